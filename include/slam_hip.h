@@ -1,0 +1,217 @@
+/*
+ * slam_hip.h — C ABI of the MI355X (gfx950) implementation of the SLAM tracker's image hot path:
+ * batched image pyramid, normalised-cross-correlation template search (matchFeatureInArea and the
+ * coarse-to-fine Feature::track walk) and FAST-9-16 corner detection with non-max suppression.
+ *
+ * Conventions
+ *   - Every function returns 0 (SLAM_HIP_OK) or a negative SLAM_HIP_E* code; nothing throws.
+ *     slam_hip_last_error_string() gives the text of the last failure on a context.
+ *   - Plain pointers and sizes only.  `h_` / unprefixed pointers are host memory, `d_` pointers are
+ *     device (HIP) memory on the context's device.  The caller owns every buffer it passes.
+ *   - One slam_ctx per (host thread, device); calls on one context are not internally locked.
+ *     The `_d` entry points only enqueue work on the context's stream and return; the host-table
+ *     entry points upload, run, download and synchronise.
+ *   - Images are 8-bit single channel, row-major, `pitch` bytes between rows (a cv::Mat ROI's
+ *     `step`), `frame_stride` bytes between the frames of a batch.
+ *   - Masks follow the reference's contract: patch masks hold 0 or 1 (feature.cpp:97-98 produces
+ *     exactly that); the host-table entry points reject other values with SLAM_HIP_EINVAL, the
+ *     `_d` entry points treat any non-zero byte as 1.  Area masks are only tested for non-zero
+ *     (matching.cpp:66,86,161,175).
+ *
+ * Each entry point names the reference interface it replaces (file:line in the reference tree).
+ */
+#ifndef SLAM_HIP_H
+#define SLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_HIP_OK       0
+#define SLAM_HIP_EINVAL  (-1)   /* bad argument (null pointer, non-positive size, bad mask value ...) */
+#define SLAM_HIP_EHIP    (-2)   /* a HIP runtime call failed */
+#define SLAM_HIP_ENOMEM  (-3)   /* host or device allocation failed */
+#define SLAM_HIP_ECAP    (-4)   /* an output capacity was exceeded (results truncated) */
+
+#define SLAM_HIP_MAX_LEVELS 8
+
+typedef struct slam_ctx slam_ctx;
+typedef struct slam_pyr slam_pyr;
+
+/* ---------------------------------------------------------------------------------------------
+ * Context.  The reference has no device boundary; its only state on this path is the SLAM object
+ * (SLAM.hpp:14-125).  A context binds one GPU and one HIP stream.
+ * ------------------------------------------------------------------------------------------- */
+int slam_hip_create(int device, slam_ctx** out);
+int slam_hip_destroy(slam_ctx* ctx);
+/* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the context's own. */
+int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream);
+int slam_hip_synchronize(slam_ctx* ctx);
+/* Text of the last error on ctx (or of the last failed slam_hip_create when ctx is NULL). */
+const char* slam_hip_last_error_string(const slam_ctx* ctx);
+
+/* Device-memory helpers for hosts that do not link a HIP runtime themselves (synchronous). */
+int slam_hip_malloc(slam_ctx* ctx, size_t bytes, void** d_ptr);
+int slam_hip_free(slam_ctx* ctx, void* d_ptr);
+int slam_hip_memcpy_h2d(slam_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int slam_hip_memcpy_d2h(slam_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---------------------------------------------------------------------------------------------
+ * Image pyramid — replaces ImagePyramid<T>::ImagePyramid (imagePyramid.hpp:15-30), batched over
+ * nframes frames of equal size.  Level i is a copy of the frame when subs[i] == 1 (here: an
+ * alias of the caller's frames, not a copy) and otherwise cv::resize(full, Size(round(w/sub),
+ * round(h/sub))) computed directly from the full-resolution frame.  subs must be increasing.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct slam_level_desc {
+    uint8_t* d_data;        /* device pointer to frame 0 of this level */
+    int32_t  w, h;
+    size_t   pitch;         /* bytes between rows */
+    size_t   frame_stride;  /* bytes between frames */
+    float    sub;
+} slam_level_desc;
+
+int slam_hip_pyramid_create(slam_ctx* ctx, int w, int h, int nlev, const float* subs,
+                            int nframes, slam_pyr** out);
+int slam_hip_pyramid_destroy(slam_ctx* ctx, slam_pyr* pyr);
+/* Build all levels from frames already in device memory (asynchronous).  d_frames must stay
+ * valid while the pyramid is used: levels with sub == 1 alias it. */
+int slam_hip_pyramid_build_d(slam_ctx* ctx, slam_pyr* pyr, const uint8_t* d_frames,
+                             size_t pitch, size_t frame_stride);
+/* Build from host frames: uploads into a buffer the pyramid owns, builds, synchronises. */
+int slam_hip_pyramid_build(slam_ctx* ctx, slam_pyr* pyr, const uint8_t* h_frames,
+                           size_t pitch, size_t frame_stride);
+int slam_hip_pyramid_level(const slam_pyr* pyr, int level, slam_level_desc* out);
+/* Copy one level of one frame to the host (ImagePyramid::images[level], imagePyramid.hpp:12). */
+int slam_hip_pyramid_download(slam_ctx* ctx, const slam_pyr* pyr, int level, int frame,
+                              uint8_t* h_dst, size_t dst_pitch);
+
+/* ---------------------------------------------------------------------------------------------
+ * Template search — replaces SLAM::matchFeatureInArea (SLAM.hpp:92-98, matching.cpp:9-228).
+ * A job is one call of the reference function on one pyramid level of one frame.  Patch, patch
+ * mask and area mask live in a byte blob (rows packed: pitch = their width) at the given offsets;
+ * an offset of -1 means "absent" (NULL in the reference).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct slam_match_job {
+    int32_t frame, level;
+    int32_t pw, ph;                 /* patch size (matching.cpp:36-37) */
+    int64_t patch_off;              /* patch,      pitch pw */
+    int64_t pmask_off;              /* patchMask,  pitch pw, or -1 */
+    int32_t ax, ay, aw, ah;         /* areaRect as passed, uncropped (matching.cpp:12) */
+    int64_t amask_off;              /* areaMask,   pitch aw, or -1 */
+    int32_t stride;
+    int32_t use_exact_area_mask;    /* matching.cpp:15,157 */
+    int64_t score_off;              /* float index into the optional score buffer, or -1 */
+} slam_match_job;
+
+typedef struct slam_match_result {
+    int32_t x, y;       /* returned Point2i (matching.cpp:222-227); (0,0) when the area misses the image */
+    float   response;   /* matching.cpp:224; -1 when the area misses the image (matching.cpp:26-30) */
+    float   dx, dy;     /* sub-pixel offset of the peak in [-0.5, 0.5]; not in the reference */
+    int32_t status;     /* 0, or SLAM_HIP_EINVAL when the job's fields are unusable */
+} slam_match_result;
+
+/* Host tables: jobs, blob and results in host memory.  The pyramid must have been built. */
+int slam_hip_match_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_match_job* jobs, int njobs,
+                         const uint8_t* blob, size_t blob_bytes, slam_match_result* out);
+/* Device tables, asynchronous, allocates nothing.  Offsets are checked against blob_bytes on the
+ * device (a job that reaches outside gets status SLAM_HIP_EINVAL).  d_scores (scores_len floats) may
+ * be NULL; when given, each job with score_off >= 0 also writes its cropped score map (row-major,
+ * pitch = cropped width) there. */
+int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_match_job* d_jobs,
+                           int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                           float* d_scores, size_t scores_len, slam_match_result* d_out);
+/* The reference call itself, one image, host pointers with pitches (NULL masks allowed):
+ * SLAM::matchFeatureInArea(im, patch, patchMask, areaRect, areaMask, stride, response, exact). */
+int slam_hip_match_feature_in_area(slam_ctx* ctx,
+                                   const uint8_t* im, int w, int h, size_t im_pitch,
+                                   const uint8_t* patch, int pw, int ph, size_t patch_pitch,
+                                   const uint8_t* patch_mask, size_t pmask_pitch,
+                                   int area_x, int area_y, int area_w, int area_h,
+                                   const uint8_t* area_mask, size_t amask_pitch,
+                                   int stride, int use_exact_area_mask,
+                                   float* h_scores /* optional: area_w*area_h floats */,
+                                   slam_match_result* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Coarse-to-fine tracking — replaces the level loop of SLAM::Feature::track (SLAM.hpp:62-65,
+ * feature.cpp:117-172), one job per feature, all levels walked on the device.  The job carries
+ * the projected template and its mask (the outputs of Feature::project, feature.cpp:109) at full
+ * resolution and the predicted point p2d (feature.cpp:117); per level the template is resized on
+ * the device (feature.cpp:130-131), the window is placed by the radius rule (feature.cpp:133-146),
+ * matched (feature.cpp:147-149) and the walk stops early when response < 0.67*threshold
+ * (feature.cpp:151-152).  The pyramid's subs are the `pyramid.subsamples` of the reference.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct slam_track_job {
+    int32_t frame;
+    int32_t projw, projh;           /* size of proj; 0 = empty projection (feature.cpp:112-115) */
+    int64_t proj_off, mask_off;     /* proj and proj_mask in the blob, pitch projw */
+    float   px, py;                 /* state.project(p3d) */
+    float   threshold;
+    int32_t stride;
+} slam_track_job;
+
+typedef struct slam_track_result {
+    int32_t x, y;        /* returned Point2i; (-1,-1) for an empty projection */
+    float   response;
+    float   dx, dy;      /* sub-pixel offset at the last level run, in that level's pixels */
+    int32_t levels_run;
+    int32_t status;
+} slam_track_result;
+
+int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs,
+                         const uint8_t* blob, size_t blob_bytes, slam_track_result* out);
+int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs,
+                           int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                           slam_track_result* d_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Corner detection — replaces cv::FAST(im, keypoints, threshold, nonmaxSuppression) as called by
+ * SLAM::getSortedKeyPoints (new_point.cpp:120) and that function itself (SLAM.hpp:118-119,
+ * new_point.cpp:113-127).  Keypoints come out in cv::FAST's order (row-major); the remaining
+ * cv::KeyPoint fields are constants (size 7, angle -1, octave 0, class_id -1).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct slam_keypoint {
+    float x, y;         /* KeyPoint::pt */
+    float response;     /* corner score */
+} slam_keypoint;
+
+/* Scratch bytes slam_hip_fast_detect_d needs for this shape (device memory, caller-allocated). */
+size_t slam_hip_fast_scratch_bytes(int w, int h, int nframes, int cap_per_frame);
+/* Device frames, asynchronous.  d_out holds nframes*cap_per_frame keypoints, d_counts nframes
+ * ints (the number FOUND per frame; when it exceeds cap_per_frame the frame's list is truncated). */
+int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, int w, int h, size_t pitch,
+                           size_t frame_stride, int nframes, int threshold, int nonmax,
+                           slam_keypoint* d_out, int cap_per_frame, int32_t* d_counts,
+                           void* d_scratch, size_t scratch_bytes);
+/* Host frames; returns SLAM_HIP_ECAP (after filling out/counts) if any frame was truncated. */
+int slam_hip_fast_detect(slam_ctx* ctx, const uint8_t* h_frames, int w, int h, size_t pitch,
+                         size_t frame_stride, int nframes, int threshold, int nonmax,
+                         slam_keypoint* out, int cap_per_frame, int32_t* counts);
+/* SLAM::getSortedKeyPoints(im, nMinPts, out): *fast_threshold is SLAM::fastThreshold (in/out).
+ * Sorted by response descending; ties by y then x ascending (std::sort leaves them unspecified).
+ * *n_out = keypoints found; at most cap are written. */
+int slam_hip_get_sorted_keypoints(slam_ctx* ctx, const uint8_t* im, int w, int h, size_t pitch,
+                                  size_t n_min_pts, float* fast_threshold,
+                                  slam_keypoint* out, int cap, int32_t* n_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Diagnostics (used by the parity tests; no reference counterpart).
+ * ------------------------------------------------------------------------------------------- */
+/* Evaluates the two score formulas of matching.cpp on the device for n triples of exact integer
+ * sums (CC = <I,P>, SI = |I|^2, SP = |P|^2): f32_out = cc/(i2*p2) (matching.cpp:70-72),
+ * mt_out = matchTemplate CV_TM_CCORR_NORMED normalisation (matching.cpp:152). */
+int slam_hip_debug_score_formulas(slam_ctx* ctx, const uint64_t* cc, const uint64_t* si,
+                                  const uint64_t* sp, int n, float* f32_out, float* mt_out);
+/* cv::resize(src, dst, Size(dw, dh)) (INTER_LINEAR) of one host image on the device. */
+int slam_hip_debug_resize(slam_ctx* ctx, const uint8_t* src, int sw, int sh, size_t spitch,
+                          uint8_t* dst, int dw, int dh, size_t dpitch);
+/* Library build identification: "slam_hip <version> gfx950". */
+const char* slam_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_HIP_H */

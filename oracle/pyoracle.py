@@ -1,0 +1,253 @@
+"""ctypes loader for the CPU oracle (oracle/slam_oracle.c) — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+All image arguments are C-contiguous uint8 numpy arrays (rows = height).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libslam_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (seconds)."""
+    src = [os.path.join(_HERE, f) for f in ("slam_oracle.c", "slam_oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or any(
+            os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+class MatchOut(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("response", C.c_float),
+                ("dx", C.c_float), ("dy", C.c_float),
+                ("aw", C.c_int), ("ah", C.c_int), ("ax", C.c_int), ("ay", C.c_int)]
+
+
+class TrackOut(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("response", C.c_float),
+                ("dx", C.c_float), ("dy", C.c_float), ("levels_run", C.c_int)]
+
+
+class KeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("response", C.c_float)]
+
+
+class PropCase(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("pw", C.c_int), ("ph", C.c_int),
+                ("xpatch", C.c_int), ("ypatch", C.c_int),
+                ("ax", C.c_int), ("ay", C.c_int), ("aw", C.c_int), ("ah", C.c_int),
+                ("im", C.POINTER(C.c_uint8)), ("patch", C.POINTER(C.c_uint8)),
+                ("patch_mask", C.POINTER(C.c_uint8)), ("area_mask", C.POINTER(C.c_uint8))]
+
+
+_u8p = C.POINTER(C.c_uint8)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.so_pyramid_level_size.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.so_pyramid_level_size.restype = None
+        L.so_resize_u8_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_ssize_t]
+        L.so_resize_u8_linear.restype = C.c_int
+        L.so_match_feature_in_area.argtypes = [
+            C.c_void_p, C.c_int, C.c_int, C.c_ssize_t,
+            C.c_void_p, C.c_int, C.c_int, C.c_ssize_t,
+            C.c_void_p, C.c_ssize_t,
+            C.c_int, C.c_int, C.c_int, C.c_int,
+            C.c_void_p, C.c_ssize_t,
+            C.c_int, C.c_int, C.c_void_p, C.POINTER(MatchOut)]
+        L.so_match_feature_in_area.restype = C.c_int
+        L.so_track.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.POINTER(C.c_float), C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                               C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(TrackOut)]
+        L.so_track.restype = C.c_int
+        L.so_fast_score_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p]
+        L.so_fast_score_map.restype = None
+        L.so_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int,
+                              C.POINTER(KeyPoint), C.c_int]
+        L.so_fast.restype = C.c_int
+        L.so_get_sorted_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_size_t,
+                                              C.POINTER(C.c_float), C.POINTER(KeyPoint), C.c_int]
+        L.so_get_sorted_keypoints.restype = C.c_int
+        L.so_proptest_srand.argtypes = [C.c_uint]
+        L.so_proptest_srand.restype = None
+        L.so_proptest_next.argtypes = [C.c_int, C.c_int, C.POINTER(PropCase)]
+        L.so_proptest_next.restype = None
+        L.so_proptest_free.argtypes = [C.POINTER(PropCase)]
+        L.so_proptest_free.restype = None
+        L.so_proptest_accept.argtypes = [C.POINTER(PropCase), C.c_int, C.c_int, C.c_float]
+        L.so_proptest_accept.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+def pyramid_level_size(w, h, sub):
+    dw, dh = C.c_int(), C.c_int()
+    lib().so_pyramid_level_size(w, h, C.c_float(sub), C.byref(dw), C.byref(dh))
+    return dw.value, dh.value
+
+
+def resize(src, dw, dh):
+    src = _u8(src)
+    dst = np.empty((dh, dw), np.uint8)
+    rc = lib().so_resize_u8_linear(src.ctypes.data, src.shape[1], src.shape[0], src.strides[0],
+                                   dst.ctypes.data, dw, dh, dw)
+    if rc != 0:
+        raise ValueError("so_resize_u8_linear failed")
+    return dst
+
+
+def pyramid(im, subs):
+    """ImagePyramid(im, subs).images as a list of arrays."""
+    im = _u8(im)
+    h, w = im.shape
+    out = []
+    for i, s in enumerate(subs):
+        if i:
+            assert subs[i - 1] < s
+        if np.float32(s) == 1:
+            out.append(im.copy())
+        else:
+            dw, dh = pyramid_level_size(w, h, s)
+            out.append(resize(im, dw, dh))
+    return out
+
+
+def match(im, patch, patch_mask, area, area_mask, stride, exact=False, want_score=False):
+    """matchFeatureInArea.  area = (x, y, w, h).  Returns dict(x, y, response, dx, dy[, score])."""
+    im = _u8(im)
+    patch = _u8(patch)
+    pm = _u8(patch_mask) if patch_mask is not None else None
+    am = _u8(area_mask) if area_mask is not None else None
+    if pm is not None:
+        assert pm.shape == patch.shape
+    if am is not None:
+        assert am.shape == (area[3], area[2])
+    out = MatchOut()
+    score = np.full((max(area[3], 1), max(area[2], 1)), np.nan, np.float32) if want_score else None
+    rc = lib().so_match_feature_in_area(
+        im.ctypes.data, im.shape[1], im.shape[0], im.strides[0],
+        patch.ctypes.data, patch.shape[1], patch.shape[0], patch.strides[0],
+        pm.ctypes.data if pm is not None else None, pm.strides[0] if pm is not None else 0,
+        area[0], area[1], area[2], area[3],
+        am.ctypes.data if am is not None else None, am.strides[0] if am is not None else 0,
+        stride, int(bool(exact)), score.ctypes.data if want_score else None, C.byref(out))
+    if rc != 0:
+        raise ValueError("so_match_feature_in_area: bad arguments")
+    r = dict(x=out.x, y=out.y, response=out.response, dx=out.dx, dy=out.dy,
+             ax=out.ax, ay=out.ay, aw=out.aw, ah=out.ah)
+    if want_score:
+        r["score"] = score.reshape(-1)[:out.aw * out.ah].reshape(out.ah, out.aw).copy()
+    return r
+
+
+def track(levels, subs, proj, proj_mask, px, py, threshold, stride):
+    """Feature::track after project(): levels = pyramid images, proj/proj_mask full-res template."""
+    levels = [_u8(l) for l in levels]
+    n = len(levels)
+    ptrs = (C.c_void_p * n)(*[l.ctypes.data for l in levels])
+    lw = (C.c_int * n)(*[l.shape[1] for l in levels])
+    lh = (C.c_int * n)(*[l.shape[0] for l in levels])
+    fs = (C.c_float * n)(*[float(s) for s in subs])
+    proj = _u8(proj)
+    pm = _u8(proj_mask)
+    assert pm.shape == proj.shape
+    out = TrackOut()
+    rc = lib().so_track(ptrs, lw, lh, fs, n, proj.ctypes.data, pm.ctypes.data,
+                        proj.shape[1], proj.shape[0], C.c_float(px), C.c_float(py),
+                        C.c_float(threshold), stride, C.byref(out))
+    if rc != 0:
+        raise ValueError("so_track: bad arguments")
+    return dict(x=out.x, y=out.y, response=out.response, dx=out.dx, dy=out.dy,
+                levels_run=out.levels_run)
+
+
+def fast_score_map(im):
+    im = _u8(im)
+    out = np.zeros(im.shape, np.int16)
+    lib().so_fast_score_map(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], out.ctypes.data)
+    return out
+
+
+def _kps(buf, n):
+    a = np.frombuffer(buf, dtype=np.float32, count=3 * n).reshape(n, 3).copy()
+    return a  # columns x, y, response
+
+
+def fast(im, threshold, nonmax=True):
+    im = _u8(im)
+    cap = im.size
+    buf = (KeyPoint * max(cap, 1))()
+    n = lib().so_fast(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], int(threshold),
+                      int(bool(nonmax)), buf, cap)
+    if n < 0:
+        raise MemoryError
+    return _kps(buf, min(n, cap))
+
+
+def get_sorted_keypoints(im, n_min_pts, fast_threshold):
+    """Returns (keypoints[n,3] sorted, new fastThreshold)."""
+    im = _u8(im)
+    cap = im.size
+    buf = (KeyPoint * max(cap, 1))()
+    f = C.c_float(fast_threshold)
+    n = lib().so_get_sorted_keypoints(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0],
+                                      n_min_pts, C.byref(f), buf, cap)
+    if n < 0:
+        raise MemoryError
+    return _kps(buf, min(n, cap)), f.value
+
+
+class PropTest:
+    """Iterator over the trials of tests/test_matching.cpp (same glibc rand() stream)."""
+
+    def __init__(self, use_area_mask, use_patch_mask, seed=1):
+        self.uam, self.upm = int(use_area_mask), int(use_patch_mask)
+        lib().so_proptest_srand(seed)
+
+    def next(self):
+        c = PropCase()
+        lib().so_proptest_next(self.uam, self.upm, C.byref(c))
+
+        def arr(p, h, w):
+            if not p:
+                return None
+            return np.ctypeslib.as_array(p, shape=(h, w)).copy()
+        case = dict(w=c.w, h=c.h, pw=c.pw, ph=c.ph, xpatch=c.xpatch, ypatch=c.ypatch,
+                    area=(c.ax, c.ay, c.aw, c.ah),
+                    im=arr(c.im, c.h, c.w), patch=arr(c.patch, c.ph, c.pw),
+                    patch_mask=arr(c.patch_mask, c.ph, c.pw),
+                    area_mask=arr(c.area_mask, c.ah, c.aw))
+        lib().so_proptest_free(C.byref(c))
+        return case
+
+    @staticmethod
+    def accept(case, mx, my, response):
+        c = PropCase()
+        c.w, c.h, c.pw, c.ph = case["w"], case["h"], case["pw"], case["ph"]
+        c.xpatch, c.ypatch = case["xpatch"], case["ypatch"]
+        keep = [np.ascontiguousarray(case["im"]), np.ascontiguousarray(case["patch"])]
+        c.im = keep[0].ctypes.data_as(_u8p)
+        c.patch = keep[1].ctypes.data_as(_u8p)
+        if case["patch_mask"] is not None:
+            keep.append(np.ascontiguousarray(case["patch_mask"]))
+            c.patch_mask = keep[-1].ctypes.data_as(_u8p)
+        return bool(lib().so_proptest_accept(C.byref(c), int(mx), int(my), C.c_float(response)))

@@ -1,0 +1,570 @@
+/*
+ * CPU oracle for the SLAM image hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ * See slam_oracle.h for scope, the reference lines each function follows and the parity
+ * pinning statement.  Plain C99, single thread, no dependencies.
+ *
+ * Build without FP contraction (-ffp-contract=off): every float/double operation below is meant
+ * to be one IEEE-754 round-to-nearest operation, in the order written.
+ */
+#include "slam_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+
+/* OpenCV cvFloor / cvRound (round-half-even under the default rounding mode) / saturate_cast */
+static inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+static inline int cv_round(double v) { return (int)lrint(v); }
+static inline short sat_s16(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+/* common.hpp:62-66 and imagePyramid.hpp:27: C round(), half away from zero, on a double */
+static inline int c_round_to_int(double v) { return (int)round(v); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* cv::resize, INTER_LINEAR, CV_8UC1  (used by imagePyramid.hpp:27, feature.cpp:130-131)        */
+/* ------------------------------------------------------------------------------------------ */
+
+#define SO_COEF_BITS 11
+#define SO_COEF_SCALE (1 << SO_COEF_BITS)
+
+void so_pyramid_level_size(int w, int h, float sub, int* dw, int* dh) {
+    /* imagePyramid.hpp:27: round(w/sub): int/float -> float, promoted to double for round() */
+    float fw = (float)w / sub;
+    float fh = (float)h / sub;
+    *dw = c_round_to_int((double)fw);
+    *dh = c_round_to_int((double)fh);
+}
+
+int so_resize_u8_linear(const uint8_t* src, int sw, int sh, ptrdiff_t spitch,
+                        uint8_t* dst, int dw, int dh, ptrdiff_t dpitch) {
+    if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return -1;
+    /* resize(): inv_scale = dsize/ssize, scale = 1/inv_scale, both double */
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+
+    int* xofs = (int*)malloc(sizeof(int) * (size_t)dw);
+    short* ialpha = (short*)malloc(sizeof(short) * 2 * (size_t)dw);
+    int* rows[2];
+    rows[0] = (int*)malloc(sizeof(int) * (size_t)dw);
+    rows[1] = (int*)malloc(sizeof(int) * (size_t)dw);
+    if (!xofs || !ialpha || !rows[0] || !rows[1]) { free(xofs); free(ialpha); free(rows[0]); free(rows[1]); return -1; }
+
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_s16(cv_round((1.f - fx) * SO_COEF_SCALE));
+        ialpha[2 * dx + 1] = sat_s16(cv_round(fx * SO_COEF_SCALE));
+    }
+
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        const short b0 = sat_s16(cv_round((1.f - fy) * SO_COEF_SCALE));
+        const short b1 = sat_s16(cv_round(fy * SO_COEF_SCALE));
+        for (int k = 0; k < 2; k++) {
+            int r = sy + k;
+            r = r < 0 ? 0 : (r > sh - 1 ? sh - 1 : r);
+            const uint8_t* S = src + (ptrdiff_t)r * spitch;
+            int* D = rows[k];
+            for (int dx = 0; dx < dw; dx++) {
+                const int sx = xofs[dx];
+                if (sx >= sw - 1)
+                    D[dx] = S[sw - 1] * SO_COEF_SCALE;       /* HResizeLinear tail: S[sx]*ONE */
+                else
+                    D[dx] = S[sx] * ialpha[2 * dx] + S[sx + 1] * ialpha[2 * dx + 1];
+            }
+        }
+        uint8_t* out = dst + (ptrdiff_t)dy * dpitch;
+        for (int dx = 0; dx < dw; dx++)   /* VResizeLinear<uchar,int,short,FixedPtCast<..,22>> */
+            out[dx] = (uint8_t)((((b0 * (rows[0][dx] >> 4)) >> 16) + ((b1 * (rows[1][dx] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(ialpha); free(rows[0]); free(rows[1]);
+    return 0;
+}
+
+int so_pyramid_build(const uint8_t* im, int w, int h, ptrdiff_t pitch,
+                     int nlev, const float* subs, uint8_t** levels) {
+    for (int i = 0; i < nlev; i++) {
+        if (i != 0 && !(subs[i - 1] < subs[i])) return -1;    /* imagePyramid.hpp:20-21 assert */
+        const float sub = subs[i];
+        if (sub == 1) {                                        /* imagePyramid.hpp:24-25 clone */
+            for (int y = 0; y < h; y++) memcpy(levels[i] + (size_t)y * w, im + (ptrdiff_t)y * pitch, (size_t)w);
+        } else {
+            int dw, dh;
+            so_pyramid_level_size(w, h, sub, &dw, &dh);
+            if (so_resize_u8_linear(im, w, h, pitch, levels[i], dw, dh, dw) != 0) return -1;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* matchFeatureInArea (matching.cpp:9-228)                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline unsigned sat_mul_u8(unsigned a, unsigned m) {   /* Mat::mul on CV_8U saturates */
+    unsigned v = a * m;
+    return v > 255u ? 255u : v;
+}
+
+/* Exact integer sums over a rows x cols rectangle:
+ *   Im = I.mul(M) (or I when M == NULL);  CC = Im.dot(P0);  SI = |Im|^2;  SP = |P0|^2
+ * P0 is the already-masked patch (matching.cpp:58), or the plain patch in the unmasked modes. */
+static void rect_sums(const uint8_t* I, ptrdiff_t ip, const uint8_t* P0, ptrdiff_t pp,
+                      const uint8_t* M, ptrdiff_t mp, int rows, int cols,
+                      uint64_t* CC, uint64_t* SI, uint64_t* SP) {
+    uint64_t cc = 0, si = 0, sp = 0;
+    for (int r = 0; r < rows; r++) {
+        const uint8_t* ir = I + (ptrdiff_t)r * ip;
+        const uint8_t* pr = P0 + (ptrdiff_t)r * pp;
+        uint32_t c = 0, s = 0, q = 0;
+        if (M) {
+            const uint8_t* mr = M + (ptrdiff_t)r * mp;
+            for (int x = 0; x < cols; x++) {
+                const unsigned v = sat_mul_u8(ir[x], mr[x]);
+                c += v * pr[x]; s += v * v; q += (unsigned)pr[x] * pr[x];
+            }
+        } else {
+            for (int x = 0; x < cols; x++) {
+                const unsigned v = ir[x];
+                c += v * pr[x]; s += v * v; q += (unsigned)pr[x] * pr[x];
+            }
+        }
+        cc += c; si += s; sp += q;
+    }
+    *CC = cc; *SI = si; *SP = sp;
+}
+
+/* matching.cpp:70-72 / :97-100: float cc = dot; float i2 = norm; float p2 = norm; cc/(i2*p2).
+ * cv::norm(NORM_L2) and Mat::dot on CV_8U accumulate exactly and return double. */
+static inline float score_f32(uint64_t CC, uint64_t SI, uint64_t SP) {
+    const float cc = (float)(double)CC;
+    const float i2 = (float)sqrt((double)SI);
+    const float p2 = (float)sqrt((double)SP);
+    const float den = i2 * p2;
+    return cc / den;
+}
+
+/* cv::matchTemplate(CV_TM_CCORR_NORMED), one channel (matching.cpp:152).  The numerator is the
+ * exact integer correlation (OpenCV computes it with a float DFT; its rounding noise is not
+ * reproducible and not restated) and the template norm is sqrt of the exact sum of squares. */
+static inline float score_mt(uint64_t CC, uint64_t SI, uint64_t SP) {
+    double num = (double)CC;
+    const double tn = sqrt((double)SP);
+    const double t = sqrt((double)SI) * tn;
+    if (fabs(num) < t) num /= t;
+    else if (fabs(num) < t * 1.125) num = num > 0 ? 1 : -1;
+    else num = 0;
+    return (float)num;
+}
+
+int so_match_feature_in_area(const uint8_t* im, int w, int h, ptrdiff_t ipitch,
+                             const uint8_t* patch, int pw, int ph, ptrdiff_t ppitch,
+                             const uint8_t* patch_mask, ptrdiff_t mpitch,
+                             int area_x, int area_y, int area_w, int area_h,
+                             const uint8_t* area_mask, ptrdiff_t ampitch,
+                             int stride, int use_exact_area_mask,
+                             float* score_out, so_match_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (stride < 1 || pw < 1 || ph < 1 || w < 1 || h < 1) return -1;
+
+    /* matching.cpp:17-30: crop the area to the image */
+    int ax = imax(area_x, 0), ay = imax(area_y, 0);
+    const int aw = imin(w - ax, area_w + area_x - ax);
+    const int ah = imin(h - ay, area_h + area_y - ay);
+    out->ax = ax; out->ay = ay; out->aw = aw; out->ah = ah;
+    if (ax >= w || ay >= h || ax + aw <= 0 || ay + ah <= 0 || aw <= 0 || ah <= 0) {
+        /* (aw<=0 / ah<=0 with the origin inside the image would hand OpenCV an empty Mat; it is
+         * folded into the reference's own reject branch) */
+        out->response = -1.f; out->x = 0; out->y = 0; out->aw = 0; out->ah = 0;
+        return 0;
+    }
+    /* matching.cpp:31-35 */
+    const uint8_t* amask0 = area_mask ? area_mask + (ptrdiff_t)(ay - area_y) * ampitch + (ax - area_x) : NULL;
+    /* matching.cpp:36-39 */
+    const int x0 = ax - pw / 2, y0 = ay - ph / 2;
+    /* matching.cpp:44-49 */
+    const int x0ua = imax(x0, 0), x1ua = imin(w, x0 + aw + pw - 1);
+    const int y0ua = imax(y0, 0), y1ua = imin(h, y0 + ah + ph - 1);
+    const int xl0 = x0ua - x0, xl1 = x1ua - x0 - pw + 1;
+    const int yl0 = y0ua - y0, yl1 = y1ua - y0 - ph + 1;
+
+    float* score = score_out ? score_out : (float*)malloc(sizeof(float) * (size_t)aw * ah);
+    if (!score) return -1;
+    for (size_t i = 0; i < (size_t)aw * ah; i++) score[i] = -1.f;   /* matching.cpp:53 */
+#define SCORE(y, x) score[(size_t)(y) * aw + (x)]
+#define AMASK(y, x) amask0[(ptrdiff_t)(y) * ampitch + (x)]
+
+    uint8_t* patch0 = NULL;   /* patch.mul(patchMask), matching.cpp:58 */
+    if (patch_mask) {
+        patch0 = (uint8_t*)malloc((size_t)pw * ph);
+        if (!patch0) { if (!score_out) free(score); return -1; }
+        for (int r = 0; r < ph; r++)
+            for (int c = 0; c < pw; c++)
+                patch0[(size_t)r * pw + c] = (uint8_t)sat_mul_u8(patch[(ptrdiff_t)r * ppitch + c], patch_mask[(ptrdiff_t)r * mpitch + c]);
+    }
+    const uint8_t* P0 = patch_mask ? patch0 : patch;
+    const ptrdiff_t p0pitch = patch_mask ? pw : ppitch;
+    uint64_t CC, SI, SP, SPfull;
+    {   /* norm(patch0) (matching.cpp:63,109) / template norm of matchTemplate */
+        uint64_t d0, d1;
+        rect_sums(P0, p0pitch, P0, p0pitch, NULL, 0, ph, pw, &d0, &d1, &SPfull);
+    }
+
+    if (patch_mask) {
+        /* interior lattice, matching.cpp:62-74 / :108-119 */
+        for (int x = xl0; x < xl1; x += stride)
+            for (int y = yl0; y < yl1; y += stride)
+                if (!area_mask || AMASK(y, x)) {
+                    rect_sums(im + (ptrdiff_t)(y0 + y) * ipitch + (x0 + x), ipitch, P0, p0pitch,
+                              patch_mask, mpitch, ph, pw, &CC, &SI, &SP);
+                    SCORE(y, x) = score_f32(CC, SI, SPfull);
+                }
+    } else {
+        /* matching.cpp:151-153: every interior cell, stride ignored */
+        if (xl1 - xl0 > 0 && yl1 - yl0 > 0)
+            for (int y = yl0; y < yl1; y++)
+                for (int x = xl0; x < xl1; x++) {
+                    rect_sums(im + (ptrdiff_t)(y0 + y) * ipitch + (x0 + x), ipitch, P0, p0pitch,
+                              NULL, 0, ph, pw, &CC, &SI, &SP);
+                    SCORE(y, x) = score_mt(CC, SI, SPfull);
+                }
+        /* matching.cpp:157-163 */
+        if (area_mask && use_exact_area_mask)
+            for (int x = xl0; x < xl1; ++x)
+                for (int y = yl0; y < yl1; ++y)
+                    if (!AMASK(y, x)) SCORE(y, x) = -1.f;
+    }
+
+    /* border lattice, matching.cpp:76-104 / :121-147 / :165-190 / :194-217 (identical shape) */
+    for (int x = 0; x < aw; x += stride) {
+        const int dl = imax(0, -x0 - x);
+        const int dr = imax(0, x0 + x + pw - w);
+        for (int y = 0; y < ah; y += stride) {
+            if (yl0 <= y && y < yl1 && xl0 <= x && x < xl1) {
+                if (yl1 >= ah) break;
+                else y = yl1;
+            }
+            if (area_mask && !AMASK(y, x)) continue;
+            const int dt = imax(0, -y0 - y);
+            const int db = imax(0, y0 + y + ph - h);
+            if (dt + db < ph && dr + dl < pw) {
+                rect_sums(im + (ptrdiff_t)(y0 + y + dt) * ipitch + (x0 + x + dl), ipitch,
+                          P0 + (ptrdiff_t)dt * p0pitch + dl, p0pitch,
+                          patch_mask ? patch_mask + (ptrdiff_t)dt * mpitch + dl : NULL, mpitch,
+                          ph - dt - db, pw - dl - dr, &CC, &SI, &SP);
+                SCORE(y, x) = score_f32(CC, SI, SP);   /* p2 recomputed on the crop (:99) */
+            }
+        }
+    }
+
+    /* cv::minMaxLoc(score, NULL, &max, NULL, &loc), matching.cpp:221-227: strict '>' from
+     * -FLT_MAX in row-major order; NaN never compares greater.  A map in which nothing compares
+     * (all NaN) reports max = 0 at (-1,-1), as cv::minMaxIdx does when no index was found. */
+    float best = -FLT_MAX;
+    long besti = -1;
+    for (long i = 0; i < (long)aw * ah; i++)
+        if (score[i] > best) { best = score[i]; besti = i; }
+    int lx, ly;
+    if (besti < 0) { lx = -1; ly = -1; out->response = 0.f; }
+    else { lx = (int)(besti % aw); ly = (int)(besti / aw); out->response = best; }
+    out->x = lx + ax;
+    out->y = ly + ay;
+
+    /* sub-pixel refinement: NOT in the reference; parabola through the two neighbours, f32. */
+    out->dx = 0.f; out->dy = 0.f;
+    if (besti >= 0) {
+        const float s = best;
+        if (lx - 1 >= 0 && lx + 1 < aw) {
+            const float sl = SCORE(ly, lx - 1), sr = SCORE(ly, lx + 1);
+            if (sl != -1.f && sr != -1.f && sl == sl && sr == sr) {
+                const float d2 = (sl + sr) - 2.0f * s;
+                if (d2 < 0.f) {
+                    float o = (sl - sr) / (2.0f * d2);
+                    out->dx = o < -0.5f ? -0.5f : (o > 0.5f ? 0.5f : o);
+                }
+            }
+        }
+        if (ly - 1 >= 0 && ly + 1 < ah) {
+            const float su = SCORE(ly - 1, lx), sd = SCORE(ly + 1, lx);
+            if (su != -1.f && sd != -1.f && su == su && sd == sd) {
+                const float d2 = (su + sd) - 2.0f * s;
+                if (d2 < 0.f) {
+                    float o = (su - sd) / (2.0f * d2);
+                    out->dy = o < -0.5f ? -0.5f : (o > 0.5f ? 0.5f : o);
+                }
+            }
+        }
+    }
+#undef SCORE
+#undef AMASK
+    free(patch0);
+    if (!score_out) free(score);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Feature::track (feature.cpp:117-172), after project()                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+int so_track(uint8_t* const* levels, const int* lw, const int* lh, const float* subs, int nlev,
+             const uint8_t* proj, const uint8_t* proj_mask, int projw, int projh,
+             float px, float py, float threshold, int stride, so_track_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (nlev < 1 || stride < 1) return -1;
+    if (projw <= 0 || projh <= 0) {                 /* feature.cpp:112-115 */
+        out->response = -1.f; out->x = -1; out->y = -1;
+        return 0;
+    }
+    const float fullResSearchRad = 20;              /* feature.cpp:119 */
+    float tx = px, ty = py;                         /* trackedPoint, feature.cpp:122 */
+    float response = 0.f, searchRad;
+    uint8_t* tbuf = (uint8_t*)malloc((size_t)projw * projh);
+    uint8_t* mbuf = (uint8_t*)malloc((size_t)projw * projh);
+    if (!tbuf || !mbuf) { free(tbuf); free(mbuf); return -1; }
+    for (int iSub = nlev - 1; iSub >= 0; --iSub) {
+        const float sub = subs[iSub];
+        const uint8_t *totrack, *totrack_mask;
+        int tw, th;
+        if (sub == 1) {                             /* feature.cpp:126-128 */
+            totrack = proj; totrack_mask = proj_mask; tw = projw; th = projh;
+        } else {                                    /* feature.cpp:130-131: Size(projw/sub, projh/sub) truncates */
+            tw = (int)((float)projw / sub);
+            th = (int)((float)projh / sub);
+            if (tw <= 0 || th <= 0) {
+                /* cv::resize would throw on an empty size; reported like an empty projection */
+                out->response = -1.f; out->x = -1; out->y = -1; out->dx = out->dy = 0.f;
+                free(tbuf); free(mbuf);
+                return 0;
+            }
+            so_resize_u8_linear(proj, projw, projh, projw, tbuf, tw, th, tw);
+            so_resize_u8_linear(proj_mask, projw, projh, projw, mbuf, tw, th, tw);
+            totrack = tbuf; totrack_mask = mbuf;
+        }
+        if (iSub == nlev - 1) {
+            searchRad = fullResSearchRad / sub;     /* feature.cpp:134 */
+        } else {
+            searchRad = (float)(1.3 * subs[iSub + 1] / sub);   /* feature.cpp:136, double expr */
+            if (iSub == 0) searchRad *= stride;     /* feature.cpp:137-138 */
+        }
+        /* feature.cpp:144-146: round() on float expressions */
+        const int rx = (int)round((double)(tx / sub - searchRad));
+        const int ry = (int)round((double)(ty / sub - searchRad));
+        const int rs = (int)round((double)(2 * searchRad + 1));
+        so_match_out m;
+        so_match_feature_in_area(levels[iSub], lw[iSub], lh[iSub], lw[iSub], totrack, tw, th, tw,
+                                 totrack_mask, tw, rx, ry, rs, rs, NULL, 0,
+                                 (iSub == 0) ? 1 : stride, 0, NULL, &m);   /* feature.cpp:147-149 */
+        response = m.response;
+        tx = (float)m.x; ty = (float)m.y;
+        tx *= sub; ty *= sub;                       /* feature.cpp:150 */
+        out->levels_run++;
+        out->dx = m.dx; out->dy = m.dy;
+        if ((double)response < 0.67 * (double)threshold) break;   /* feature.cpp:151-152 */
+    }
+    free(tbuf); free(mbuf);
+    out->x = (int)tx; out->y = (int)ty;            /* Point2i(float,float) truncates */
+    out->response = response;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cv::FAST, 16-pixel ring, 9 contiguous (new_point.cpp:120)                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+static const int so_ring[16][2] = {   /* (dx, dy) */
+    {0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+    {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+/* A_dark = max over the 16 arcs of 9 of min(v - ring), A_bright the same on (ring - v). */
+static void fast_arcs(const uint8_t* p, ptrdiff_t pitch, int* a_dark, int* a_bright) {
+    int d[16];
+    const int v = p[0];
+    for (int k = 0; k < 16; k++) d[k] = v - p[(ptrdiff_t)so_ring[k][1] * pitch + so_ring[k][0]];
+    int ad = -256, ab = -256;
+    for (int s = 0; s < 16; s++) {
+        int mn = 256, mx = -256;
+        for (int j = 0; j < 9; j++) {
+            const int q = d[(s + j) & 15];
+            if (q < mn) mn = q;
+            if (q > mx) mx = q;
+        }
+        if (mn > ad) ad = mn;
+        if (-mx > ab) ab = -mx;
+    }
+    *a_dark = ad; *a_bright = ab;
+}
+
+void so_fast_score_map(const uint8_t* im, int w, int h, ptrdiff_t pitch, int16_t* score) {
+    memset(score, 0, sizeof(int16_t) * (size_t)w * h);
+    for (int y = 3; y < h - 3; y++)
+        for (int x = 3; x < w - 3; x++) {
+            int ad, ab;
+            fast_arcs(im + (ptrdiff_t)y * pitch + x, pitch, &ad, &ab);
+            const int s = imax(ad, ab) - 1;
+            score[(size_t)y * w + x] = (int16_t)(s < 0 ? 0 : s);
+        }
+}
+
+int so_fast(const uint8_t* im, int w, int h, ptrdiff_t pitch, int threshold, int nonmax,
+            so_keypoint* out, int cap) {
+    threshold = imin(imax(threshold, 0), 255);
+    if (w < 7 || h < 7) return 0;
+    /* per-pixel stored score as cv::FAST keeps it: cornerScore for corners, 0 elsewhere (uchar) */
+    uint8_t* sc = (uint8_t*)calloc((size_t)w * h, 1);
+    uint8_t* is = (uint8_t*)calloc((size_t)w * h, 1);
+    if (!sc || !is) { free(sc); free(is); return -1; }
+    for (int y = 3; y < h - 3; y++)
+        for (int x = 3; x < w - 3; x++) {
+            int ad, ab;
+            fast_arcs(im + (ptrdiff_t)y * pitch + x, pitch, &ad, &ab);
+            if (ad > threshold || ab > threshold) {          /* 9 contiguous |diff| > threshold */
+                is[(size_t)y * w + x] = 1;
+                /* cornerScore<16>: a0 starts at threshold, result = max(t, arcs) - 1 */
+                sc[(size_t)y * w + x] = (uint8_t)(imax(threshold, imax(ad, ab)) - 1);
+            }
+        }
+    int n = 0;
+    for (int y = 3; y < h - 3; y++)
+        for (int x = 3; x < w - 3; x++) {
+            const size_t i = (size_t)y * w + x;
+            if (!is[i]) continue;
+            const int s = sc[i];
+            if (nonmax) {
+                if (!(s > sc[i - 1] && s > sc[i + 1] &&
+                      s > sc[i - w - 1] && s > sc[i - w] && s > sc[i - w + 1] &&
+                      s > sc[i + w - 1] && s > sc[i + w] && s > sc[i + w + 1]))
+                    continue;
+            }
+            if (n < cap) { out[n].x = (float)x; out[n].y = (float)y; out[n].response = (float)s; }
+            n++;
+        }
+    free(sc); free(is);
+    return n;
+}
+
+static int kp_cmp(const void* a, const void* b) {
+    const so_keypoint* p = (const so_keypoint*)a;
+    const so_keypoint* q = (const so_keypoint*)b;
+    if (p->response != q->response) return p->response > q->response ? -1 : 1;  /* new_point.cpp:109-111 */
+    if (p->y != q->y) return p->y < q->y ? -1 : 1;      /* std::sort is unstable: ties fixed as y, x ascending */
+    if (p->x != q->x) return p->x < q->x ? -1 : 1;
+    return 0;
+}
+
+int so_get_sorted_keypoints(const uint8_t* im, int w, int h, ptrdiff_t pitch, size_t n_min_pts,
+                            float* fast_threshold, so_keypoint* out, int cap) {
+    const size_t maxk = (size_t)w * h;
+    so_keypoint* tmp = (so_keypoint*)malloc(sizeof(so_keypoint) * (maxk ? maxk : 1));
+    if (!tmp) return -1;
+    float f = *fast_threshold;
+    size_t n = 0;
+    while (n < n_min_pts) {                             /* new_point.cpp:116-122 */
+        const int t = (int)f;                           /* FAST(..., int threshold, ...) */
+        const int r = so_fast(im, w, h, pitch, t, 1, tmp, (int)maxk);
+        n = r < 0 ? 0 : (size_t)r;
+        f *= 0.5f;
+        if (t <= 0) break;   /* the reference loops forever on a corner-poor image; stop after t = 0 */
+    }
+    f *= 2.f;                                           /* new_point.cpp:123 */
+    qsort(tmp, n, sizeof(so_keypoint), kp_cmp);         /* new_point.cpp:124 */
+    if (n > 2 * n_min_pts)                              /* new_point.cpp:125-126 */
+        f = tmp[(size_t)((double)n_min_pts * 1.9)].response;
+    *fast_threshold = f;
+    for (size_t i = 0; i < n && i < (size_t)cap; i++) out[i] = tmp[i];
+    free(tmp);
+    return (int)n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* tests/test_matching.cpp:13-101 restated                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+void so_proptest_srand(unsigned seed) { srand(seed); }
+
+void so_proptest_next(int use_area_mask, int use_patch_mask, so_proptest_case* c) {
+    memset(c, 0, sizeof(*c));
+    /* tests/test_matching.cpp:15-17.  The order in which the two rand() calls of one constructor
+     * call are evaluated is unspecified in C++; g++ (the reference's compiler, Makefile:1)
+     * evaluates call arguments right to left, which is what is done here. */
+    const int hh = rand() % 1000 + 1;
+    const int ww = rand() % 1000 + 1;
+    c->w = ww; c->h = hh;
+    const int ph = imin(rand() % imin(200, hh) + 1, hh);
+    const int pw = imin(rand() % imin(200, ww) + 1, ww);
+    c->pw = pw; c->ph = ph;
+    c->im = (uint8_t*)malloc((size_t)ww * hh);
+    c->patch = (uint8_t*)malloc((size_t)pw * ph);
+    /* :21-23, int arithmetic wraps, % truncates toward zero, store to uchar keeps the low byte */
+    for (int i = 0; i < ww; ++i)
+        for (int j = 0; j < hh; ++j) {
+            const int32_t v = (int32_t)(15485867u * (uint32_t)i + 15486883u * (uint32_t)j);
+            c->im[(size_t)j * ww + i] = (uint8_t)(v % 7907);
+        }
+    /* :26-40 */
+    const int leftpatch = pw / 2, toppatch = ph / 2;
+    const int xpatch = rand() % ww;
+    const int ypatch = rand() % hh;
+    c->xpatch = xpatch; c->ypatch = ypatch;
+    const int ptop = imax(ypatch - toppatch, 0), pleft = imax(xpatch - leftpatch, 0);
+    const int pbottom = imin(ypatch - toppatch + ph, hh);
+    const int pright = imin(xpatch - leftpatch + pw, ww);
+    const int dptop = ptop - (ypatch - toppatch), dpleft = pleft - (xpatch - leftpatch);
+    for (int i = 0; i < pw; ++i)
+        for (int j = 0; j < ph; ++j)
+            c->patch[(size_t)j * pw + i] = (uint8_t)(rand() % 255);
+    for (int y = ptop; y < pbottom; ++y)
+        for (int x = pleft; x < pright; ++x)
+            c->patch[(size_t)(dptop + y - ptop) * pw + (dpleft + x - pleft)] = c->im[(size_t)y * ww + x];
+    /* :44-46 */
+    const int x0area = xpatch - (rand() % 100), y0area = ypatch - (rand() % 100);
+    const int x1area = xpatch + (rand() % 100) + 1, y1area = ypatch + (rand() % 100) + 1;
+    c->ax = x0area; c->ay = y0area; c->aw = x1area - x0area; c->ah = y1area - y0area;
+    /* :49-58 */
+    if (use_area_mask) {
+        c->area_mask = (uint8_t*)malloc((size_t)c->aw * c->ah);
+        for (int i = 0; i < c->aw; ++i)
+            for (int j = 0; j < c->ah; ++j)
+                c->area_mask[(size_t)j * c->aw + i] = ((rand() % 255) > 128) ? 1 : 0;
+        c->area_mask[(size_t)(ypatch - y0area) * c->aw + (xpatch - x0area)] = 1;
+    }
+    /* :61-69 */
+    if (use_patch_mask) {
+        c->patch_mask = (uint8_t*)malloc((size_t)pw * ph);
+        for (int i = 0; i < pw; ++i)
+            for (int j = 0; j < ph; ++j)
+                c->patch_mask[(size_t)j * pw + i] = ((rand() % 255) > 128) ? 1 : 0;
+    }
+}
+
+void so_proptest_free(so_proptest_case* c) {
+    free(c->im); free(c->patch); free(c->patch_mask); free(c->area_mask);
+    memset(c, 0, sizeof(*c));
+}
+
+int so_proptest_accept(const so_proptest_case* c, int mx, int my, float response) {
+    if (c->xpatch == mx && c->ypatch == my) return 1;                         /* :83 */
+    if (0 > mx || 0 > my || mx >= c->w || my >= c->h || (double)response <= 0.99) return 0;   /* :86-88 */
+    const int leftpatch = c->pw / 2, toppatch = c->ph / 2;
+    for (int i = 0; i < c->pw; ++i)                                           /* :89-97 */
+        for (int j = 0; j < c->ph; ++j)
+            if (!c->patch_mask || c->patch_mask[(size_t)j * c->pw + i]) {
+                const int yim = j + my - toppatch, xim = i + mx - leftpatch;
+                if (xim >= 0 && yim >= 0 && xim < c->w && yim < c->h)
+                    if (c->patch[(size_t)j * c->pw + i] != c->im[(size_t)yim * c->w + xim]) return 0;
+            }
+    return 1;
+}

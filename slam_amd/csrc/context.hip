@@ -1,0 +1,155 @@
+// Context, error reporting, device-memory helpers and host-side resize tap tables.
+#include <cmath>
+
+#include "slam_internal.h"
+
+static char g_create_err[512] = "";
+
+int slam_set_error(slam_ctx* ctx, int code, const char* fmt, ...) {
+    char* dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* slam_hip_version(void) { return "slam_hip 0.1 gfx950"; }
+
+extern "C" const char* slam_hip_last_error_string(const slam_ctx* ctx) {
+    return ctx ? ctx->err : g_create_err;
+}
+
+extern "C" int slam_hip_create(int device, slam_ctx** out) {
+    if (!out) return slam_set_error(nullptr, SLAM_HIP_EINVAL, "slam_hip_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return slam_set_error(nullptr, SLAM_HIP_EHIP, "slam_hip_create: no HIP device (%s)",
+                              hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return slam_set_error(nullptr, SLAM_HIP_EINVAL, "slam_hip_create: device %d of %d", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return slam_set_error(nullptr, SLAM_HIP_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    slam_ctx* c = new (std::nothrow) slam_ctx();
+    if (!c) return slam_set_error(nullptr, SLAM_HIP_ENOMEM, "slam_hip_create: out of host memory");
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return slam_set_error(nullptr, SLAM_HIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_destroy(slam_ctx* ctx) {
+    if (!ctx) return SLAM_HIP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4; i++)
+        if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_synchronize(slam_ctx* ctx) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_malloc(slam_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return SLAM_HIP_EINVAL;
+    *d_ptr = nullptr;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return slam_set_error(ctx, SLAM_HIP_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_free(slam_ctx* ctx, void* d_ptr) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (!d_ptr) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipFree(d_ptr));
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_memcpy_h2d(slam_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return SLAM_HIP_EINVAL;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_memcpy_d2h(slam_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!ctx || (bytes && (!h_dst || !d_src))) return SLAM_HIP_EINVAL;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}
+
+int slam_stage_reserve(slam_ctx* ctx, int slot, size_t bytes) {
+    if (bytes <= ctx->stage_bytes[slot]) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage[slot]) {
+        SLAM_HIP_CHECK(ctx, hipFree(ctx->d_stage[slot]));
+        ctx->d_stage[slot] = nullptr;
+        ctx->stage_bytes[slot] = 0;
+    }
+    size_t want = bytes + bytes / 2 + 4096;
+    hipError_t e = hipMalloc(&ctx->d_stage[slot], want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return slam_set_error(ctx, SLAM_HIP_ENOMEM, "staging hipMalloc(%zu): %s", want, hipGetErrorString(e));
+    }
+    ctx->stage_bytes[slot] = want;
+    return SLAM_HIP_OK;
+}
+
+// cv::resize(INTER_LINEAR), CV_8U: source offset and the two 11-bit fixed-point weights of every
+// destination index.  Columns reset the fraction at the image edges (clamp_fraction), rows keep it
+// and clamp the row index when it is used.  All arithmetic follows OpenCV 2.4's resize():
+// scale = 1 / ((double)dsize / ssize); f = (float)((d + 0.5) * scale - 0.5); s = floor(f); f -= s;
+// weights = saturate_cast<short>(cvRound(w * 2048)) with round-half-even.
+void slam_resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::vector<uint32_t>& coef,
+                        bool clamp_fraction) {
+    ofs.resize(dsize);
+    coef.resize(dsize);
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        volatile double t = (d + 0.5) * scale;   // two separately rounded operations
+        float f = (float)(t - 0.5);
+        int s = (int)std::floor(f);
+        f -= (float)s;
+        if (clamp_fraction) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        long c0 = std::lrint((double)((1.f - f) * 2048.f));
+        long c1 = std::lrint((double)(f * 2048.f));
+        c0 = c0 < -32768 ? -32768 : (c0 > 32767 ? 32767 : c0);
+        c1 = c1 < -32768 ? -32768 : (c1 > 32767 ? 32767 : c1);
+        ofs[d] = s;
+        coef[d] = (uint32_t)(uint16_t)(int16_t)c0 | ((uint32_t)(uint16_t)(int16_t)c1 << 16);
+    }
+}

@@ -1,0 +1,462 @@
+// Template search kernels: one workgroup per job.
+//   match_kernel  = SLAM::matchFeatureInArea (matching.cpp:9-228) for a table of jobs
+//   track_kernel  = the level loop of SLAM::Feature::track (feature.cpp:117-172), walking the
+//                   pyramid levels of one feature inside one workgroup (each level's window depends
+//                   on the previous level's result)
+#include <cfloat>
+#include <climits>
+
+#include "match_common.h"
+
+using namespace slamdev;
+
+namespace {
+
+struct CoreOut { int x, y; float response, dx, dy; };
+
+struct CoreShared {
+    unsigned long long red64[SLAM_WG / 64];
+    float bestv[SLAM_WG / 64];
+    int besti[SLAM_WG / 64];
+    unsigned long long spfull;
+    float nb[4];        // neighbour scores for the sub-pixel fit
+    int nbok[4];
+    CoreOut out;
+};
+
+// Reference-exact search of one job by direct evaluation: every score cell the reference visits is
+// computed by one lane looping over the template pixels.
+__device__ CoreOut match_core_direct(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    // |patch0|^2 over the whole template (matching.cpp:63,109; template norm of matchTemplate)
+    {
+        unsigned long long sp = 0;
+        const int n = t.tw * t.th;
+        for (int i = tid; i < n; i += SLAM_WG) {
+            unsigned p, m;
+            tmpl_fetch(t, i / t.tw, i % t.tw, p, m);
+            p *= m;
+            sp += p * p;
+        }
+        sp = wave_sum_u64(sp);
+        if (lane == 0) sm.red64[wid] = sp;
+        __syncthreads();
+        if (tid == 0) sm.spfull = sm.red64[0] + sm.red64[1] + sm.red64[2] + sm.red64[3];
+        __syncthreads();
+    }
+    const unsigned long long spfull = sm.spfull;
+
+    Best b = {-FLT_MAX, INT_MAX};
+    const int ncell = g.aw * g.ah;
+    for (int c = tid; c < ncell; c += SLAM_WG) {
+        const int x = c % g.aw, y = c / g.aw;
+        const int kind = classify_cell(g, x, y);
+        float sc = -1.f;                                   // matching.cpp:53
+        if (kind != CELL_NONE) {
+            int dl = 0, dr = 0, dt = 0, db = 0;
+            if (kind == CELL_F32_CROP) {
+                dl = max(0, -g.x0 - x); dr = max(0, g.x0 + x + g.pw - g.w);
+                dt = max(0, -g.y0 - y); db = max(0, g.y0 + y + g.ph - g.h);
+            }
+            const Sums s = cell_sums_partial(g, t, g.x0 + x, g.y0 + y, dl, g.pw - dr, dt, g.ph - db, 0, 1);
+            sc = (kind == CELL_MT) ? score_mt(s.cc, s.si, spfull)
+               : (kind == CELL_F32_FULL) ? score_f32(s.cc, s.si, spfull)
+                                         : score_f32(s.cc, s.si, s.sp);
+        }
+        if (scores) scores[c] = sc;
+        best_update(b, sc, c);
+    }
+    b = best_wave(b);
+    if (lane == 0) { sm.bestv[wid] = b.v; sm.besti[wid] = b.idx; }
+    __syncthreads();
+    Best bb = {sm.bestv[0], sm.besti[0]};
+#pragma unroll
+    for (int k = 1; k < SLAM_WG / 64; k++) {
+        const float ov = sm.bestv[k]; const int oi = sm.besti[k];
+        if (ov > bb.v || (ov == bb.v && oi < bb.idx)) { bb.v = ov; bb.idx = oi; }
+    }
+
+    // sub-pixel fit: the four neighbours of the peak, one wavefront each
+    const bool found = bb.idx != INT_MAX;
+    const int lx = found ? bb.idx % g.aw : -1, ly = found ? bb.idx / g.aw : -1;
+    {
+        const int nx = lx + (wid == 0 ? -1 : wid == 1 ? 1 : 0);
+        const int ny = ly + (wid == 2 ? -1 : wid == 3 ? 1 : 0);
+        const bool inside = found && nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
+        float sc = -1.f;
+        if (inside) {
+            const int kind = classify_cell(g, nx, ny);
+            if (kind != CELL_NONE) {
+                int dl = 0, dr = 0, dt = 0, db = 0;
+                if (kind == CELL_F32_CROP) {
+                    dl = max(0, -g.x0 - nx); dr = max(0, g.x0 + nx + g.pw - g.w);
+                    dt = max(0, -g.y0 - ny); db = max(0, g.y0 + ny + g.ph - g.h);
+                }
+                Sums s = cell_sums_partial(g, t, g.x0 + nx, g.y0 + ny, dl, g.pw - dr, dt, g.ph - db, lane, 64);
+                s.cc = wave_sum_u64(s.cc); s.si = wave_sum_u64(s.si); s.sp = wave_sum_u64(s.sp);
+                sc = (kind == CELL_MT) ? score_mt(s.cc, s.si, spfull)
+                   : (kind == CELL_F32_FULL) ? score_f32(s.cc, s.si, spfull)
+                                             : score_f32(s.cc, s.si, s.sp);
+            }
+        }
+        if (lane == 0) { sm.nb[wid] = sc; sm.nbok[wid] = inside ? 1 : 0; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        CoreOut o;
+        o.dx = 0.f; o.dy = 0.f;
+        if (!found) {            // nothing compared greater than -FLT_MAX: every cell is NaN
+            o.x = -1 + g.ax; o.y = -1 + g.ay; o.response = 0.f;
+        } else {
+            o.x = lx + g.ax; o.y = ly + g.ay; o.response = bb.v;
+            const float s = bb.v;
+            const float sl = sm.nb[0], sr = sm.nb[1], su = sm.nb[2], sd = sm.nb[3];
+            if (sm.nbok[0] && sm.nbok[1] && sl != -1.f && sr != -1.f && sl == sl && sr == sr) {
+                const float d2 = __fsub_rn(__fadd_rn(sl, sr), __fmul_rn(2.0f, s));
+                if (d2 < 0.f) {
+                    const float q = __fdiv_rn(__fsub_rn(sl, sr), __fmul_rn(2.0f, d2));
+                    o.dx = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
+                }
+            }
+            if (sm.nbok[2] && sm.nbok[3] && su != -1.f && sd != -1.f && su == su && sd == sd) {
+                const float d2 = __fsub_rn(__fadd_rn(su, sd), __fmul_rn(2.0f, s));
+                if (d2 < 0.f) {
+                    const float q = __fdiv_rn(__fsub_rn(su, sd), __fmul_rn(2.0f, d2));
+                    o.dy = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
+                }
+            }
+        }
+        sm.out = o;
+    }
+    __syncthreads();
+    const CoreOut r = sm.out;
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ bool span_ok(long long off, long long len, unsigned long long total) {
+    return off >= 0 && len >= 0 && (unsigned long long)off <= total && (unsigned long long)len <= total - (unsigned long long)off;
+}
+
+__global__ __launch_bounds__(SLAM_WG) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_bytes, float* scores,
+                                                        unsigned long long scores_len,
+                                                        slam_match_result* __restrict__ out) {
+    __shared__ CoreShared sm;
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_match_job job = jobs[j];
+    bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.level >= 0 && job.level < pyr.nlev &&
+              job.pw >= 1 && job.ph >= 1 && job.pw <= 32767 && job.ph <= 32767 && job.stride >= 1 &&
+              job.aw <= (1 << 20) && job.ah <= (1 << 20) &&
+              job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28);
+    const long long pbytes = (long long)job.pw * job.ph;
+    ok = ok && span_ok(job.patch_off, pbytes, blob_bytes);
+    if (job.pmask_off != -1) ok = ok && span_ok(job.pmask_off, pbytes, blob_bytes);
+    if (job.amask_off != -1) ok = ok && job.aw >= 1 && job.ah >= 1 && span_ok(job.amask_off, (long long)job.aw * job.ah, blob_bytes);
+    if (!ok) {
+        if (threadIdx.x == 0) { slam_match_result r = {0, 0, -1.f, 0.f, 0.f, SLAM_HIP_EINVAL}; out[j] = r; }
+        return;
+    }
+    int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
+#pragma unroll
+    for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++)
+        if (l == job.level) { lw = pyr.lev[l].w; lh = pyr.lev[l].h; lp = pyr.lev[l].pitch; ls = pyr.lev[l].frame_stride; ld = pyr.lev[l].data; }
+    const uint8_t* im = ld + (long long)job.frame * ls;
+    const Geo g = make_geo(im, lw, lh, lp, job.pw, job.ph, job.ax, job.ay, job.aw, job.ah,
+                           job.amask_off != -1 ? blob + job.amask_off : nullptr, job.stride,
+                           job.pmask_off != -1, job.use_exact_area_mask != 0);
+    if (g.reject) {   // matching.cpp:26-30
+        if (threadIdx.x == 0) { slam_match_result r = {0, 0, -1.f, 0.f, 0.f, SLAM_HIP_OK}; out[j] = r; }
+        return;
+    }
+    float* sc = nullptr;
+    if (scores && job.score_off >= 0) {
+        if (!span_ok(job.score_off, (long long)g.aw * g.ah, scores_len)) {
+            if (threadIdx.x == 0) { slam_match_result r = {0, 0, -1.f, 0.f, 0.f, SLAM_HIP_EINVAL}; out[j] = r; }
+            return;
+        }
+        sc = scores + job.score_off;
+    }
+    Tmpl t;
+    t.patch = blob + job.patch_off;
+    t.mask = job.pmask_off != -1 ? blob + job.pmask_off : nullptr;
+    t.srcw = job.pw; t.srch = job.ph; t.tw = job.pw; t.th = job.ph; t.resized = false;
+    t.xofs = nullptr; t.xcoef = nullptr; t.yofs = nullptr; t.ycoef = nullptr;
+    const CoreOut o = match_core_direct(g, t, sc, sm);
+    if (threadIdx.x == 0) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
+}
+
+__global__ __launch_bounds__(SLAM_WG) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_bytes,
+                                                        slam_track_result* __restrict__ out) {
+    __shared__ CoreShared sm;
+    __shared__ int s_xofs[SLAM_MAX_TMPL], s_yofs[SLAM_MAX_TMPL];
+    __shared__ unsigned s_xcoef[SLAM_MAX_TMPL], s_ycoef[SLAM_MAX_TMPL];
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_track_job job = jobs[j];
+    const int tid = threadIdx.x;
+    if (job.projw <= 0 || job.projh <= 0) {   // feature.cpp:112-115
+        if (tid == 0) { slam_track_result r = {-1, -1, -1.f, 0.f, 0.f, 0, SLAM_HIP_OK}; out[j] = r; }
+        return;
+    }
+    const long long pbytes = (long long)job.projw * job.projh;
+    const bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.projw <= SLAM_MAX_TMPL && job.projh <= SLAM_MAX_TMPL &&
+                    job.stride >= 1 && job.stride <= 1024 &&
+                    span_ok(job.proj_off, pbytes, blob_bytes) && span_ok(job.mask_off, pbytes, blob_bytes) &&
+                    fabsf(job.px) < 1e7f && fabsf(job.py) < 1e7f && job.threshold == job.threshold;
+    if (!ok) {
+        if (tid == 0) { slam_track_result r = {-1, -1, -1.f, 0.f, 0.f, 0, SLAM_HIP_EINVAL}; out[j] = r; }
+        return;
+    }
+    Tmpl t;
+    t.patch = blob + job.proj_off; t.mask = blob + job.mask_off;
+    t.srcw = job.projw; t.srch = job.projh;
+    t.xofs = s_xofs; t.xcoef = s_xcoef; t.yofs = s_yofs; t.ycoef = s_ycoef;
+
+    float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
+    float response = 0.f, sdx = 0.f, sdy = 0.f;
+    int levels_run = 0;
+    bool empty_level = false;
+    for (int i = pyr.nlev - 1; i >= 0; --i) {
+        float sub = 1.f, subnext = 1.f;
+        int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
+#pragma unroll
+        for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++) {
+            if (l == i) { sub = pyr.lev[l].sub; lw = pyr.lev[l].w; lh = pyr.lev[l].h; lp = pyr.lev[l].pitch; ls = pyr.lev[l].frame_stride; ld = pyr.lev[l].data; }
+            if (l == i + 1) subnext = pyr.lev[l].sub;
+        }
+        if (sub == 1.f) {                        // feature.cpp:126-128
+            t.tw = job.projw; t.th = job.projh; t.resized = false;
+        } else {                                 // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
+            t.tw = (int)__fdiv_rn((float)job.projw, sub);
+            t.th = (int)__fdiv_rn((float)job.projh, sub);
+            t.resized = true;
+            if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
+            __syncthreads();                     // the previous level no longer reads the tables
+            for (int d = tid; d < t.tw; d += SLAM_WG) resize_tap(d, job.projw, t.tw, true, s_xofs[d], s_xcoef[d]);
+            for (int d = tid; d < t.th; d += SLAM_WG) resize_tap(d, job.projh, t.th, false, s_yofs[d], s_ycoef[d]);
+            __syncthreads();
+        }
+        float searchRad;
+        if (i == pyr.nlev - 1) {
+            searchRad = __fdiv_rn(20.f, sub);    // feature.cpp:119,134
+        } else {                                 // feature.cpp:136-138: double expression stored to float
+            searchRad = (float)__ddiv_rn(__dmul_rn(1.3, (double)subnext), (double)sub);
+            if (i == 0) searchRad = __fmul_rn(searchRad, (float)job.stride);
+        }
+        // feature.cpp:144-146
+        const int rx = (int)round((double)__fsub_rn(__fdiv_rn(tx, sub), searchRad));
+        const int ry = (int)round((double)__fsub_rn(__fdiv_rn(ty, sub), searchRad));
+        const int rs = (int)round((double)__fadd_rn(__fmul_rn(2.f, searchRad), 1.f));
+        const Geo g = make_geo(ld + (long long)job.frame * ls, lw, lh, lp, t.tw, t.th, rx, ry, rs, rs,
+                               nullptr, (i == 0) ? 1 : job.stride, true, false);   // feature.cpp:147-149
+        int mx = 0, my = 0;
+        sdx = 0.f; sdy = 0.f;
+        if (g.reject) { response = -1.f; }       // matching.cpp:26-30
+        else {
+            const CoreOut o = match_core_direct(g, t, nullptr, sm);
+            mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
+        }
+        tx = __fmul_rn((float)mx, sub);          // feature.cpp:150
+        ty = __fmul_rn((float)my, sub);
+        levels_run++;
+        if ((double)response < __dmul_rn(0.67, (double)job.threshold)) break;   // feature.cpp:151-152
+    }
+    if (tid == 0) {
+        slam_track_result r;
+        if (empty_level) { r.x = -1; r.y = -1; r.response = -1.f; r.dx = 0.f; r.dy = 0.f; r.levels_run = levels_run; }
+        else { r.x = (int)tx; r.y = (int)ty; r.response = response; r.dx = sdx; r.dy = sdy; r.levels_run = levels_run; }
+        r.status = SLAM_HIP_OK;
+        out[j] = r;
+    }
+}
+
+__global__ void score_formula_kernel(const unsigned long long* cc, const unsigned long long* si,
+                                     const unsigned long long* sp, int n, float* f32o, float* mto) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f32o[i] = score_f32(cc[i], si[i], sp[i]);
+    mto[i] = score_mt(cc[i], si[i], sp[i]);
+}
+
+int check_pyr(slam_ctx* ctx, const slam_pyr* pyr, const char* who) {
+    if (!pyr || !pyr->built) return slam_set_error(ctx, SLAM_HIP_EINVAL, "%s: pyramid not built", who);
+    if (pyr->device != ctx->device) return slam_set_error(ctx, SLAM_HIP_EINVAL, "%s: pyramid belongs to device %d", who, pyr->device);
+    return SLAM_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_match_job* d_jobs,
+                                      int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                                      float* d_scores, size_t scores_len, slam_match_result* d_out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!d_jobs || !d_blob || !d_out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_batch: null table or negative count");
+    int rc = check_pyr(ctx, pyr, "match_batch");
+    if (rc != SLAM_HIP_OK) return rc;
+    if (njobs == 0) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), 0, ctx->stream, pyr->dev, d_jobs, njobs,
+                       d_blob, (unsigned long long)blob_bytes, d_scores, (unsigned long long)scores_len, d_out);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    return SLAM_HIP_OK;
+}
+
+static int mask_is_01(const uint8_t* m, size_t n) {
+    for (size_t i = 0; i < n; i++) if (m[i] > 1) return 0;
+    return 1;
+}
+
+static int match_batch_host(slam_ctx* ctx, const slam_pyr* pyr, const slam_match_job* jobs, int njobs,
+                            const uint8_t* blob, size_t blob_bytes, float* h_scores, size_t scores_len,
+                            slam_match_result* out) {
+    if (njobs < 0 || (njobs > 0 && (!jobs || !blob || !out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_batch: null table or negative count");
+    int rc = check_pyr(ctx, pyr, "match_batch");
+    if (rc != SLAM_HIP_OK) return rc;
+    if (njobs == 0) return SLAM_HIP_OK;
+    for (int i = 0; i < njobs; i++) {   // the reference's mask contract: patch masks hold 0 or 1
+        const slam_match_job& jb = jobs[i];
+        if (jb.pmask_off != -1 && jb.pw >= 1 && jb.ph >= 1 && jb.pmask_off >= 0 &&
+            (unsigned long long)jb.pmask_off + (unsigned long long)jb.pw * jb.ph <= blob_bytes &&
+            !mask_is_01(blob + jb.pmask_off, (size_t)jb.pw * jb.ph))
+            return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_batch: job %d: patch mask values must be 0 or 1", i);
+    }
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t jb = sizeof(slam_match_job) * (size_t)njobs, rb = sizeof(slam_match_result) * (size_t)njobs;
+    if ((rc = slam_stage_reserve(ctx, 0, jb)) || (rc = slam_stage_reserve(ctx, 1, blob_bytes + 16)) ||
+        (rc = slam_stage_reserve(ctx, 2, rb)) || (h_scores && (rc = slam_stage_reserve(ctx, 3, scores_len * 4))))
+        return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[0], jobs, jb, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[1], blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = slam_hip_match_batch_d(ctx, pyr, (const slam_match_job*)ctx->d_stage[0], njobs,
+                                (const uint8_t*)ctx->d_stage[1], blob_bytes,
+                                h_scores ? (float*)ctx->d_stage[3] : nullptr, scores_len,
+                                (slam_match_result*)ctx->d_stage[2]);
+    if (rc != SLAM_HIP_OK) return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_stage[2], rb, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_scores) SLAM_HIP_CHECK(ctx, hipMemcpyAsync(h_scores, ctx->d_stage[3], scores_len * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_match_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_match_job* jobs, int njobs,
+                                    const uint8_t* blob, size_t blob_bytes, slam_match_result* out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    return match_batch_host(ctx, pyr, jobs, njobs, blob, blob_bytes, nullptr, 0, out);
+}
+
+extern "C" int slam_hip_match_feature_in_area(slam_ctx* ctx,
+                                              const uint8_t* im, int w, int h, size_t im_pitch,
+                                              const uint8_t* patch, int pw, int ph, size_t patch_pitch,
+                                              const uint8_t* patch_mask, size_t pmask_pitch,
+                                              int area_x, int area_y, int area_w, int area_h,
+                                              const uint8_t* area_mask, size_t amask_pitch,
+                                              int stride, int use_exact_area_mask,
+                                              float* h_scores, slam_match_result* out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (!im || !patch || !out || w < 1 || h < 1 || pw < 1 || ph < 1 || stride < 1 ||
+        im_pitch < (size_t)w || patch_pitch < (size_t)pw || (patch_mask && pmask_pitch < (size_t)pw) ||
+        (area_mask && (area_w < 1 || area_h < 1 || amask_pitch < (size_t)area_w)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_feature_in_area: bad arguments");
+    const float one = 1.f;
+    slam_pyr* pyr = nullptr;
+    int rc = slam_hip_pyramid_create(ctx, w, h, 1, &one, 1, &pyr);
+    if (rc != SLAM_HIP_OK) return rc;
+    rc = slam_hip_pyramid_build(ctx, pyr, im, im_pitch, im_pitch * (size_t)h);
+    if (rc == SLAM_HIP_OK) {
+        const size_t pb = (size_t)pw * ph, ab = area_mask ? (size_t)area_w * area_h : 0;
+        std::vector<uint8_t> blob(pb * (patch_mask ? 2 : 1) + ab);
+        for (int r = 0; r < ph; r++) memcpy(&blob[(size_t)r * pw], patch + (size_t)r * patch_pitch, (size_t)pw);
+        if (patch_mask) for (int r = 0; r < ph; r++) memcpy(&blob[pb + (size_t)r * pw], patch_mask + (size_t)r * pmask_pitch, (size_t)pw);
+        const size_t aoff = pb * (patch_mask ? 2 : 1);
+        if (area_mask) for (int r = 0; r < area_h; r++) memcpy(&blob[aoff + (size_t)r * area_w], area_mask + (size_t)r * amask_pitch, (size_t)area_w);
+        slam_match_job job;
+        job.frame = 0; job.level = 0; job.pw = pw; job.ph = ph;
+        job.patch_off = 0; job.pmask_off = patch_mask ? (int64_t)pb : -1;
+        job.ax = area_x; job.ay = area_y; job.aw = area_w; job.ah = area_h;
+        job.amask_off = area_mask ? (int64_t)aoff : -1;
+        job.stride = stride; job.use_exact_area_mask = use_exact_area_mask;
+        job.score_off = h_scores ? 0 : -1;
+        const size_t slen = h_scores ? (size_t)(area_w > 0 ? area_w : 0) * (size_t)(area_h > 0 ? area_h : 0) : 0;
+        rc = match_batch_host(ctx, pyr, &job, 1, blob.data(), blob.size(), slen ? h_scores : nullptr, slen, out);
+    }
+    slam_hip_pyramid_destroy(ctx, pyr);
+    return rc;
+}
+
+extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs,
+                                      int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                                      slam_track_result* d_out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!d_jobs || !d_blob || !d_out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch: null table or negative count");
+    int rc = check_pyr(ctx, pyr, "track_batch");
+    if (rc != SLAM_HIP_OK) return rc;
+    if (njobs == 0) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), 0, ctx->stream, pyr->dev, d_jobs, njobs,
+                       d_blob, (unsigned long long)blob_bytes, d_out);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs,
+                                    const uint8_t* blob, size_t blob_bytes, slam_track_result* out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!jobs || !blob || !out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch: null table or negative count");
+    int rc = check_pyr(ctx, pyr, "track_batch");
+    if (rc != SLAM_HIP_OK) return rc;
+    if (njobs == 0) return SLAM_HIP_OK;
+    for (int i = 0; i < njobs; i++) {
+        const slam_track_job& jb = jobs[i];
+        if (jb.projw >= 1 && jb.projh >= 1 && jb.mask_off >= 0 &&
+            (unsigned long long)jb.mask_off + (unsigned long long)jb.projw * jb.projh <= blob_bytes &&
+            !mask_is_01(blob + jb.mask_off, (size_t)jb.projw * jb.projh))
+            return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch: job %d: mask values must be 0 or 1", i);
+    }
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t jb = sizeof(slam_track_job) * (size_t)njobs, rb = sizeof(slam_track_result) * (size_t)njobs;
+    if ((rc = slam_stage_reserve(ctx, 0, jb)) || (rc = slam_stage_reserve(ctx, 1, blob_bytes + 16)) ||
+        (rc = slam_stage_reserve(ctx, 2, rb)))
+        return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[0], jobs, jb, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[1], blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = slam_hip_track_batch_d(ctx, pyr, (const slam_track_job*)ctx->d_stage[0], njobs,
+                                (const uint8_t*)ctx->d_stage[1], blob_bytes, (slam_track_result*)ctx->d_stage[2]);
+    if (rc != SLAM_HIP_OK) return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_stage[2], rb, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_debug_score_formulas(slam_ctx* ctx, const uint64_t* cc, const uint64_t* si,
+                                             const uint64_t* sp, int n, float* f32_out, float* mt_out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (n < 0 || (n > 0 && (!cc || !si || !sp || !f32_out || !mt_out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "debug_score_formulas: bad arguments");
+    if (n == 0) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t b8 = (size_t)n * 8, b4 = (size_t)n * 4;
+    int rc = slam_stage_reserve(ctx, 0, 3 * b8 + 2 * b4);
+    if (rc != SLAM_HIP_OK) return rc;
+    uint8_t* base = (uint8_t*)ctx->d_stage[0];
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(base, cc, b8, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(base + b8, si, b8, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(base + 2 * b8, sp, b8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(score_formula_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream,
+                       (const unsigned long long*)base, (const unsigned long long*)(base + b8),
+                       (const unsigned long long*)(base + 2 * b8), n, (float*)(base + 3 * b8), (float*)(base + 3 * b8 + b4));
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(f32_out, base + 3 * b8, b4, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(mt_out, base + 3 * b8 + b4, b4, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}

@@ -1,0 +1,225 @@
+// Device-side pieces shared by the template-search kernels: job geometry (matching.cpp:17-49),
+// the score-map cell classification (which cells the reference's loops visit and with which
+// formula), the two score formulas, template access (direct or resized on the fly) and the
+// workgroup argmax.  gfx950 only; wavefront = 64 lanes.
+#pragma once
+
+#include "slam_internal.h"
+
+#define SLAM_WG 256          // threads per workgroup of the search kernels (4 wavefronts)
+#define SLAM_MAX_TMPL 512    // max template width/height handled by the on-device resize tables
+
+namespace slamdev {
+
+// ---- score formulas -------------------------------------------------------------------------
+// Exact integer sums in, IEEE single/double operations out; every operation is one correctly
+// rounded step, in the order of matching.cpp:70-72 (float cc, i2, p2; cc / (i2*p2)).
+__device__ __forceinline__ float score_f32(unsigned long long CC, unsigned long long SI, unsigned long long SP) {
+    const float cc = (float)(double)CC;
+    const float i2 = (float)__dsqrt_rn((double)SI);
+    const float p2 = (float)__dsqrt_rn((double)SP);
+    const float den = __fmul_rn(i2, p2);
+    return __fdiv_rn(cc, den);
+}
+
+// cv::matchTemplate(CV_TM_CCORR_NORMED) normalisation (matching.cpp:152): double arithmetic,
+// |num| < t -> num/t, |num| < 1.125 t -> +-1, else 0.
+__device__ __forceinline__ float score_mt(unsigned long long CC, unsigned long long SI, unsigned long long SP) {
+    double num = (double)CC;
+    const double tn = __dsqrt_rn((double)SP);
+    const double t = __dmul_rn(__dsqrt_rn((double)SI), tn);
+    if (fabs(num) < t) num = __ddiv_rn(num, t);
+    else if (fabs(num) < __dmul_rn(t, 1.125)) num = num > 0 ? 1.0 : -1.0;
+    else num = 0.0;
+    return (float)num;
+}
+
+// ---- geometry -------------------------------------------------------------------------------
+struct Geo {
+    const uint8_t* im;        // level image of the job's frame
+    int w, h;
+    long long ipitch;
+    const uint8_t* amask;     // areaMask0: already offset to the cropped origin, or nullptr
+    long long ampitch;
+    int ax, ay, aw, ah;       // cropped area (matching.cpp:19-25)
+    int pw, ph;
+    int x0, y0;               // image position of patch pixel (0,0) for cell (0,0) (matching.cpp:38-39)
+    int xl0, xl1, yl0, yl1;   // cells whose whole patch is inside the image (matching.cpp:44-49)
+    int stride;
+    int yf;                   // first multiple of stride >= yl0
+    bool masked;              // patchMask given
+    bool exact;               // useExactAreaMask
+    bool reject;              // area misses the image (matching.cpp:26-30)
+};
+
+__device__ __forceinline__ Geo make_geo(const uint8_t* im, int w, int h, long long ipitch,
+                                        int pw, int ph, int ax0, int ay0, int aw0, int ah0,
+                                        const uint8_t* amask, int stride, bool masked, bool exact) {
+    Geo g;
+    g.im = im; g.w = w; g.h = h; g.ipitch = ipitch; g.pw = pw; g.ph = ph;
+    g.stride = stride; g.masked = masked; g.exact = exact;
+    const int ax = max(ax0, 0), ay = max(ay0, 0);
+    // 64-bit so that absurd rectangles cannot overflow
+    const long long awl = min((long long)w - ax, (long long)aw0 + ax0 - ax);
+    const long long ahl = min((long long)h - ay, (long long)ah0 + ay0 - ay);
+    g.ax = ax; g.ay = ay;
+    g.reject = (ax >= w) || (ay >= h) || (ax + awl <= 0) || (ay + ahl <= 0) || awl <= 0 || ahl <= 0;
+    g.aw = g.reject ? 0 : (int)awl;
+    g.ah = g.reject ? 0 : (int)ahl;
+    g.amask = amask ? amask + (long long)(ay - ay0) * aw0 + (ax - ax0) : nullptr;
+    g.ampitch = aw0;
+    g.x0 = ax - pw / 2;
+    g.y0 = ay - ph / 2;
+    const int x0ua = max(g.x0, 0), x1ua = min(w, g.x0 + g.aw + pw - 1);
+    const int y0ua = max(g.y0, 0), y1ua = min(h, g.y0 + g.ah + ph - 1);
+    g.xl0 = x0ua - g.x0; g.xl1 = x1ua - g.x0 - pw + 1;
+    g.yl0 = y0ua - g.y0; g.yl1 = y1ua - g.y0 - ph + 1;
+    g.yf = (g.yl0 + stride - 1) / stride * stride;
+    return g;
+}
+
+enum CellKind { CELL_NONE = 0, CELL_F32_FULL = 1, CELL_MT = 2, CELL_F32_CROP = 3 };
+
+// Which formula (if any) the reference's loops apply to score cell (x,y):
+//  - patchMask modes: interior lattice from (xl0,yl0) step stride (matching.cpp:64-73,110-118);
+//  - no patchMask: every interior cell through matchTemplate (matching.cpp:151-153), reset to -1
+//    where the area mask is 0 only with useExactAreaMask (matching.cpp:157-163);
+//  - border lattice from (0,0) step stride with the jump over the interior block
+//    (matching.cpp:76-104 and its three copies).
+__device__ __forceinline__ int classify_cell(const Geo& g, int x, int y) {
+    const bool inx = (x >= g.xl0) && (x < g.xl1);
+    const bool interior = inx && (y >= g.yl0) && (y < g.yl1);
+    const bool am = !g.amask || g.amask[(long long)y * g.ampitch + x] != 0;
+    if (interior) {
+        if (g.masked) {
+            if (((x - g.xl0) % g.stride) != 0 || ((y - g.yl0) % g.stride) != 0) return CELL_NONE;
+            return am ? CELL_F32_FULL : CELL_NONE;
+        }
+        if (g.exact && !am) return CELL_NONE;
+        return CELL_MT;
+    }
+    if ((x % g.stride) != 0) return CELL_NONE;
+    bool on;
+    if (inx && g.yf < g.yl1)   // this column's walk hits the interior block at yf and jumps to yl1
+        on = (y < g.yl0) ? ((y % g.stride) == 0) : ((y >= g.yl1) && (((y - g.yl1) % g.stride) == 0));
+    else
+        on = (y % g.stride) == 0;
+    if (!on || !am) return CELL_NONE;
+    const int dl = max(0, -g.x0 - x), dr = max(0, g.x0 + x + g.pw - g.w);
+    const int dt = max(0, -g.y0 - y), db = max(0, g.y0 + y + g.ph - g.h);
+    return (dt + db < g.ph && dl + dr < g.pw) ? CELL_F32_CROP : CELL_NONE;
+}
+
+// ---- template access ------------------------------------------------------------------------
+// A level template is either the job's patch as stored (sub == 1) or cv::resize of it to
+// (tw, th) evaluated on demand from tap tables in LDS (feature.cpp:130-131).
+struct Tmpl {
+    const uint8_t* patch;     // source patch, pitch srcw
+    const uint8_t* mask;      // source mask (0 / non-zero), or nullptr
+    int srcw, srch;
+    int tw, th;               // size at this level
+    bool resized;
+    const int* xofs; const unsigned* xcoef;   // LDS tables when resized
+    const int* yofs; const unsigned* ycoef;
+};
+
+__device__ __forceinline__ int resize_px(const uint8_t* S, int sw, int sh, int sx, unsigned xc, int sy, unsigned yc, bool binarize) {
+    const int a0 = (int)(short)(xc & 0xffff), a1 = (int)(short)(xc >> 16);
+    const int b0 = (int)(short)(yc & 0xffff), b1 = (int)(short)(yc >> 16);
+    const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
+    const int sx1 = min(sx + 1, sw - 1);
+    int p00 = S[(long long)r0 * sw + sx], p01 = S[(long long)r0 * sw + sx1];
+    int p10 = S[(long long)r1 * sw + sx], p11 = S[(long long)r1 * sw + sx1];
+    if (binarize) { p00 = p00 != 0; p01 = p01 != 0; p10 = p10 != 0; p11 = p11 != 0; }
+    const int h0 = p00 * a0 + p01 * a1;
+    const int h1 = p10 * a0 + p11 * a1;
+    return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+}
+
+// patch value and mask bit (0/1) of template pixel (row u, column v)
+__device__ __forceinline__ void tmpl_fetch(const Tmpl& t, int u, int v, unsigned& p, unsigned& m) {
+    if (!t.resized) {
+        p = t.patch[(long long)u * t.srcw + v];
+        m = t.mask ? (t.mask[(long long)u * t.srcw + v] != 0) : 1u;
+    } else {
+        const int sx = t.xofs[v], sy = t.yofs[u];
+        const unsigned xc = t.xcoef[v], yc = t.ycoef[u];
+        p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, xc, sy, yc, false);
+        m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, xc, sy, yc, true) != 0) : 1u;
+    }
+}
+
+// One entry of cv::resize's tap tables, computed on the device with the same double/float steps
+// as OpenCV's resize(): scale = 1/((double)dsize/ssize); f = (float)((d+0.5)*scale - 0.5);
+// s = floor(f); f -= s; weights = round-half-even((1-f)*2048), (f*2048).
+__device__ __forceinline__ void resize_tap(int d, int ssize, int dsize, bool clamp_fraction, int& ofs, unsigned& coef) {
+    const double inv_scale = __ddiv_rn((double)dsize, (double)ssize);
+    const double scale = __ddiv_rn(1.0, inv_scale);
+    const double t = __dmul_rn((double)d + 0.5, scale);
+    float f = (float)__dadd_rn(t, -0.5);
+    int s = (int)floorf(f);
+    f = __fsub_rn(f, (float)s);
+    if (clamp_fraction) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    }
+    int c0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+    int c1 = __float2int_rn(__fmul_rn(f, 2048.f));
+    c0 = min(max(c0, -32768), 32767);
+    c1 = min(max(c1, -32768), 32767);
+    ofs = s;
+    coef = (unsigned)(unsigned short)(short)c0 | ((unsigned)(unsigned short)(short)c1 << 16);
+}
+
+// ---- sums over one cell ---------------------------------------------------------------------
+struct Sums { unsigned long long cc, si, sp; };
+
+// Sum over template rows [r0,r1) x columns [c0,c1) for the cell whose patch origin is image pixel
+// (ix, iy); the caller guarantees the rectangle lies inside the image.  `lane`/`nlanes` split the
+// pixels among cooperating lanes (each returns its partial sums).
+__device__ __forceinline__ Sums cell_sums_partial(const Geo& g, const Tmpl& t, int ix, int iy,
+                                                  int c0, int c1, int r0, int r1, int lane, int nlanes) {
+    Sums s = {0ull, 0ull, 0ull};
+    const int cw = c1 - c0;
+    const int n = cw * (r1 - r0);
+    for (int i = lane; i < n; i += nlanes) {
+        const int u = r0 + i / cw, v = c0 + i % cw;
+        unsigned p, m;
+        tmpl_fetch(t, u, v, p, m);
+        const unsigned I = g.im[(long long)(iy + u) * g.ipitch + (ix + v)] * m;
+        const unsigned P = p * m;
+        s.cc += I * P; s.si += I * I; s.sp += P * P;
+    }
+    return s;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o, 64);
+        const unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
+        v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+
+// ---- argmax ---------------------------------------------------------------------------------
+// cv::minMaxLoc semantics: strict '>' from -FLT_MAX in row-major order, so among equal maxima
+// the smallest linear index wins and NaN never wins.
+struct Best { float v; int idx; };
+
+__device__ __forceinline__ void best_update(Best& b, float v, int idx) {
+    if (v > b.v || (v == b.v && idx < b.idx)) { b.v = v; b.idx = idx; }
+}
+
+__device__ __forceinline__ Best best_wave(Best b) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(b.v, o, 64);
+        const int oi = __shfl_xor(b.idx, o, 64);
+        if (ov > b.v || (ov == b.v && oi < b.idx)) { b.v = ov; b.idx = oi; }
+    }
+    return b;
+}
+
+}  // namespace slamdev

@@ -1,0 +1,81 @@
+// Internal declarations shared by the HIP translation units of libslam_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "slam_hip.h"
+
+struct slam_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // growable device staging buffers used by the host-table entry points
+    void* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+};
+
+// One level of a pyramid as the kernels see it (passed by value inside slam_pyr_dev).
+struct slam_level_dev {
+    const uint8_t* data;
+    int w, h;
+    long long pitch, frame_stride;
+    float sub;
+};
+
+struct slam_pyr_dev {
+    int nlev;
+    int nframes;
+    slam_level_dev lev[SLAM_HIP_MAX_LEVELS];
+};
+
+struct slam_pyr {
+    int device = 0;
+    int w = 0, h = 0, nlev = 0, nframes = 0;
+    float subs[SLAM_HIP_MAX_LEVELS] = {0};
+    int lw[SLAM_HIP_MAX_LEVELS] = {0}, lh[SLAM_HIP_MAX_LEVELS] = {0};
+    size_t lpitch[SLAM_HIP_MAX_LEVELS] = {0}, lstride[SLAM_HIP_MAX_LEVELS] = {0};
+    uint8_t* d_level[SLAM_HIP_MAX_LEVELS] = {nullptr};   // owned buffers (nullptr for aliased levels)
+    // bilinear tap tables per resized level, device memory: xofs[dw], xcoef[dw] (a0 | a1<<16),
+    // yofs[dh], ycoef[dh]
+    int32_t* d_xofs[SLAM_HIP_MAX_LEVELS] = {nullptr};
+    uint32_t* d_xcoef[SLAM_HIP_MAX_LEVELS] = {nullptr};
+    int32_t* d_yofs[SLAM_HIP_MAX_LEVELS] = {nullptr};
+    uint32_t* d_ycoef[SLAM_HIP_MAX_LEVELS] = {nullptr};
+    uint8_t* d_upload = nullptr;     // owned copy of host frames (slam_hip_pyramid_build)
+    size_t upload_bytes = 0;
+    const uint8_t* d_frames = nullptr;   // current level-0 source
+    size_t pitch0 = 0, stride0 = 0;
+    bool built = false;
+    slam_pyr_dev dev{};
+};
+
+int slam_set_error(slam_ctx* ctx, int code, const char* fmt, ...);
+int slam_stage_reserve(slam_ctx* ctx, int slot, size_t bytes);
+
+#define SLAM_HIP_CHECK(ctx, call)                                                              \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return slam_set_error((ctx), SLAM_HIP_EHIP, "%s failed: %s (%s:%d)", #call,        \
+                                  hipGetErrorString(e__), __FILE__, __LINE__);                 \
+    } while (0)
+
+// Bilinear tap tables of cv::resize(INTER_LINEAR) for 8-bit images, computed on the host in
+// double/float exactly as OpenCV 2.4's resize() does (11-bit fixed-point coefficients).
+void slam_resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::vector<uint32_t>& coef,
+                        bool clamp_fraction);
+
+// kernels' host launchers (defined in the .hip files)
+int slam_launch_pyramid(slam_ctx* ctx, slam_pyr* pyr);
+
+static_assert(sizeof(slam_match_job) == 72 && sizeof(slam_match_result) == 24, "ABI struct layout");
+static_assert(sizeof(slam_track_job) == 48 && sizeof(slam_track_result) == 28, "ABI struct layout");
+static_assert(sizeof(slam_keypoint) == 12, "ABI struct layout");

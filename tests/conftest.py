@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): compiled on demand with gcc."""
+    from oracle import pyoracle
+    pyoracle.build()
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One GPU context for the whole GPU test session.  No skip: without the HIP library or
+    without a GPU these tests must fail, not pass silently."""
+    from slam_amd import api
+    c = api.Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bars: positions, corner sets, pyramid bytes and score bit patterns identical; the
+north-star tolerance for NCC scores and sub-pixel offsets is 1e-4, the tests demand bit equality
+(tolerance 0) because both sides perform the same IEEE operations on exact integer sums."""
+import os
+
+import numpy as np
+import pytest
+
+from slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 0.0   # north-star allows 1e-4; bit-exact is what is asserted
+
+
+def _bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def _same_float(a, b):
+    a = np.float32(a); b = np.float32(b)
+    return (np.isnan(a) and np.isnan(b)) or a == b
+
+
+def _check_match(ctx, oracle, im, patch, pm, area, am, stride, exact=False):
+    ref = oracle.match(im, patch, pm, area, am, stride, exact, want_score=True)
+    got = api.match_feature_in_area(ctx, im, patch, pm, area, am, stride, exact, want_score=True)
+    assert got["score"].shape == ref["score"].shape
+    if ref["score"].size:
+        gb, rb = _bits(got["score"]), _bits(ref["score"])
+        nan_ok = np.isnan(got["score"]) & np.isnan(ref["score"])
+        bad = (gb != rb) & ~nan_ok
+        assert not bad.any(), "score cells differ at %s" % (np.argwhere(bad)[:5],)
+    assert (got["x"], got["y"]) == (ref["x"], ref["y"])
+    assert _same_float(got["response"], ref["response"])
+    assert _same_float(got["dx"], ref["dx"]) and _same_float(got["dy"], ref["dy"])
+    assert abs(got["dx"]) <= 0.5 and abs(got["dy"]) <= 0.5
+    return ref, got
+
+
+def test_score_formulas_bit_exact(ctx):
+    rng = np.random.default_rng(1)
+    n = 200000
+    sp = rng.integers(1, 1 << 34, n, dtype=np.uint64)
+    si = rng.integers(0, 1 << 34, n, dtype=np.uint64)
+    cc = np.minimum(rng.integers(0, 1 << 34, n, dtype=np.uint64), np.sqrt(sp.astype(np.float64) * si).astype(np.uint64))
+    # adversarial: perfect squares +-1, identical sums (exact self-match), zeros, tiny values
+    k = rng.integers(1, 1 << 17, 5000, dtype=np.uint64)
+    for d in (0, 1, -1):
+        v = (k * k + np.uint64(d) if d >= 0 else k * k - np.uint64(1))
+        cc = np.concatenate([cc, v]); si = np.concatenate([si, v]); sp = np.concatenate([sp, v])
+    cc = np.concatenate([cc, [0, 0, 5, 1]]).astype(np.uint64)
+    si = np.concatenate([si, [0, 7, 0, 1]]).astype(np.uint64)
+    sp = np.concatenate([sp, [0, 9, 9, 1]]).astype(np.uint64)
+    f32, mt = api.debug_score_formulas(ctx, cc, si, sp)
+    with np.errstate(all="ignore"):
+        c = cc.astype(np.float64).astype(np.float32)
+        i2 = np.sqrt(si.astype(np.float64)).astype(np.float32)
+        p2 = np.sqrt(sp.astype(np.float64)).astype(np.float32)
+        ref32 = c / (i2 * p2)
+        num = cc.astype(np.float64)
+        t = np.sqrt(si.astype(np.float64)) * np.sqrt(sp.astype(np.float64))
+        r = np.where(np.abs(num) < t, num / np.where(t == 0, 1, t),
+                     np.where(np.abs(num) < t * 1.125, np.where(num > 0, 1.0, -1.0), 0.0))
+        refmt = r.astype(np.float32)
+    ok32 = (_bits(f32) == _bits(ref32)) | (np.isnan(f32) & np.isnan(ref32))
+    assert ok32.all(), "f32 formula differs at %s" % np.flatnonzero(~ok32)[:5]
+    okmt = _bits(mt) == _bits(refmt)
+    assert okmt.all(), "matchTemplate formula differs at %s" % np.flatnonzero(~okmt)[:5]
+
+
+def test_resize_matches_oracle(ctx, oracle):
+    rng = np.random.default_rng(2)
+    cases = [(4, 4, 2, 2), (6, 6, 2, 2), (640, 480, 320, 240), (640, 480, 160, 120), (640, 480, 213, 160),
+             (81, 81, 27, 27), (21, 21, 10, 10), (21, 21, 5, 5), (31, 31, 3, 3), (7, 5, 13, 9), (1, 1, 3, 3),
+             (2, 9, 1, 4), (1280, 720, 160, 90)]
+    for _ in range(40):
+        sw, sh = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        cases.append((sw, sh, int(rng.integers(1, 300)), int(rng.integers(1, 300))))
+    for sw, sh, dw, dh in cases:
+        src = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        ref = oracle.resize(src, dw, dh)
+        got = api.debug_resize(ctx, src, dw, dh)
+        assert np.array_equal(got, ref), (sw, sh, dw, dh)
+
+
+@pytest.mark.parametrize("w,h,subs", [(640, 480, [1, 2, 4]), (1280, 720, [1, 2, 4, 8]), (640, 480, [1, 3]),
+                                      (333, 211, [1, 1.5, 2.5, 7]), (64, 48, [2, 3])])
+def test_pyramid_matches_oracle(ctx, oracle, w, h, subs):
+    frames = np.stack([synth.frame(w, h, 7 + i, (3 * i, 5 * i)) for i in range(3)])
+    pyr = api.ImagePyramid(ctx, frames, subs)
+    try:
+        assert pyr.nSubs() == len(subs)
+        for f in range(3):
+            ref = oracle.pyramid(frames[f], subs)
+            for l in range(len(subs)):
+                got = pyr.image(l, f)
+                assert got.shape == ref[l].shape
+                assert np.array_equal(got, ref[l]), (f, l)
+    finally:
+        pyr.close()
+
+
+def _rand_case(rng, w, h, pwmax, awmax):
+    im = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    pw, ph = int(rng.integers(1, pwmax + 1)), int(rng.integers(1, pwmax + 1))
+    patch = rng.integers(0, 256, (ph, pw), dtype=np.uint8)
+    aw, ah = int(rng.integers(1, awmax + 1)), int(rng.integers(1, awmax + 1))
+    ax, ay = int(rng.integers(-aw - 2, w + 2)), int(rng.integers(-ah - 2, h + 2))
+    return im, patch, (ax, ay, aw, ah)
+
+
+@pytest.mark.parametrize("use_pm,use_am", [(False, False), (False, True), (True, False), (True, True)])
+def test_match_random_small_all_modes(ctx, oracle, use_pm, use_am):
+    rng = np.random.default_rng(100 + 2 * use_pm + use_am)
+    for it in range(60):
+        w, h = int(rng.integers(1, 48)), int(rng.integers(1, 48))
+        im, patch, area = _rand_case(rng, w, h, 12, 20)
+        if it % 3 == 0:   # plant the patch so that high scores and exact matches occur
+            ph, pw = patch.shape
+            if pw <= w and ph <= h:
+                x = int(rng.integers(0, w - pw + 1)); y = int(rng.integers(0, h - ph + 1))
+                patch = im[y:y + ph, x:x + pw].copy()
+        pm = (rng.integers(0, 2, patch.shape, dtype=np.uint8) if use_pm else None)
+        am = (rng.integers(0, 2, (area[3], area[2]), dtype=np.uint8) if use_am else None)
+        stride = int(rng.integers(1, 5))
+        exact = bool(rng.integers(0, 2))
+        _check_match(ctx, oracle, im, patch, pm, area, am, stride, exact)
+
+
+def test_match_edge_cases(ctx, oracle):
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, (30, 40), dtype=np.uint8)
+    patch = rng.integers(0, 256, (7, 9), dtype=np.uint8)
+    # area entirely off the image: response -1, (0,0)   (matching.cpp:26-30)
+    for area in [(40, 3, 5, 5), (3, 30, 5, 5), (-9, 2, 9, 4), (2, -6, 4, 6), (100, 100, 3, 3)]:
+        ref, got = _check_match(ctx, oracle, im, patch, None, area, None, 1)
+        assert (got["x"], got["y"], got["response"]) == (0, 0, -1.0)
+    # all-zero image: every evaluated F32 cell is 0/0 = NaN, matchTemplate cells are 0
+    z = np.zeros((20, 20), np.uint8)
+    pm = np.ones((7, 9), np.uint8)
+    ref, got = _check_match(ctx, oracle, z, patch, pm, (2, 2, 12, 12), None, 1)
+    assert (got["x"], got["y"], got["response"]) == (1, 1, 0.0)      # all NaN -> (-1,-1)+area, max 0
+    _check_match(ctx, oracle, z, patch, None, (2, 2, 12, 12), None, 1)
+    # patch larger than the image, 1x1 patch, 1x1 area, stride beyond the window
+    big = rng.integers(0, 256, (50, 60), dtype=np.uint8)
+    _check_match(ctx, oracle, im, big, None, (5, 5, 10, 10), None, 1)
+    _check_match(ctx, oracle, im, big, np.ones_like(big), (5, 5, 10, 10), None, 2)
+    _check_match(ctx, oracle, im, patch[:1, :1], None, (0, 0, 40, 30), None, 1)
+    _check_match(ctx, oracle, im, patch, None, (10, 10, 1, 1), None, 1)
+    _check_match(ctx, oracle, im, patch, pm, (3, 3, 8, 8), None, 50)
+    # ties: constant image -> many equal maxima, the first in row-major order must win
+    c = np.full((25, 25), 77, np.uint8)
+    _check_match(ctx, oracle, c, np.full((5, 5), 77, np.uint8), None, (1, 1, 20, 20), None, 1)
+    _check_match(ctx, oracle, c, np.full((5, 5), 9, np.uint8), np.ones((5, 5), np.uint8), (-3, -3, 30, 30), None, 2)
+    # all-zero patch mask: SP = 0 everywhere
+    _check_match(ctx, oracle, im, patch, np.zeros_like(patch), (3, 3, 8, 8), None, 1)
+
+
+def test_match_rejects_bad_mask_values(ctx):
+    im = np.zeros((20, 20), np.uint8)
+    patch = np.ones((5, 5), np.uint8)
+    with pytest.raises(api.SlamHipError) as e:
+        api.match_feature_in_area(ctx, im, patch, np.full((5, 5), 255, np.uint8), (2, 2, 5, 5), None, 1)
+    assert e.value.code == api.capi.EINVAL
+
+
+@pytest.mark.parametrize("use_am,use_pm", [(False, False), (True, False), (False, True), (True, True)])
+def test_reference_property_test(ctx, oracle, use_am, use_pm):
+    """tests/test_matching.cpp:13-117 on the GPU path: same generator, same acceptance rule, plus
+    equality with the oracle's position and response."""
+    pt = oracle.PropTest(use_am, use_pm)
+    ntrials = int(os.environ.get("SLAM_PROP_TRIALS", "100"))
+    cases = [pt.next() for _ in range(ntrials)]
+    # small trials go through the one-call entry point with full score maps, all of them through the batch
+    for c in cases:
+        if c["w"] * c["h"] <= 80 * 80:
+            _check_match(ctx, oracle, c["im"], c["patch"], c["patch_mask"], c["area"], c["area_mask"], 1)
+    for c in cases:
+        pyr = api.ImagePyramid(ctx, c["im"], [1.0])
+        try:
+            got = api.match_batch(ctx, pyr, [dict(patch=c["patch"], patch_mask=c["patch_mask"], area=c["area"],
+                                                  area_mask=c["area_mask"], stride=1)])[0]
+        finally:
+            pyr.close()
+        assert got["status"] == 0
+        ref = oracle.match(c["im"], c["patch"], c["patch_mask"], c["area"], c["area_mask"], 1)
+        assert (got["x"], got["y"]) == (ref["x"], ref["y"])
+        assert _same_float(got["response"], ref["response"])
+        assert oracle.PropTest.accept(c, got["x"], got["y"], got["response"])
+
+
+def _c2_like_jobs(rng, w, h, nfeat, tsize, frame0, shift):
+    pts = synth.feature_grid(w, h, nfeat, tsize + 30, rng)
+    jobs = []
+    for (cx, cy) in pts:
+        proj = synth.cut_template(frame0, cx, cy, tsize, tsize)
+        mask = np.ones_like(proj)
+        if rng.integers(0, 3) == 0:      # a warped-quad-like mask: cut two corners
+            k = int(rng.integers(1, tsize // 3 + 1))
+            for r in range(k):
+                mask[r, :k - r] = 0
+                mask[tsize - 1 - r, tsize - (k - r):] = 0
+        # truth in the shifted frame + a prediction error within the search window / 3
+        tx, ty = cx - shift[0], cy - shift[1]
+        px = tx + float(rng.integers(-6, 7)) + float(rng.random()) * 0.9
+        py = ty + float(rng.integers(-6, 7)) + float(rng.random()) * 0.9
+        jobs.append(dict(frame=0, proj=proj, proj_mask=mask, px=px, py=py, threshold=0.98, stride=3, truth=(tx, ty)))
+    return jobs
+
+
+@pytest.mark.parametrize("w,h,subs,nfeat,tsize,min_found", [(640, 480, [1, 2, 4], 64, 21, 40), (640, 480, [1, 3], 24, 27, 14),
+                                                            (320, 240, [1], 16, 11, 14), (640, 360, [1, 2, 4, 8], 32, 31, 5)])
+def test_track_matches_oracle(ctx, oracle, w, h, subs, nfeat, tsize, min_found):
+    rng = np.random.default_rng(w + nfeat)
+    shift = (int(rng.integers(-6, 7)), int(rng.integers(-6, 7)))
+    f0 = synth.frame(w, h, 11)
+    f1 = synth.frame(w, h, 11, shift)
+    jobs = _c2_like_jobs(rng, w, h, nfeat, tsize, f0, shift)
+    # some features near / over the border and one empty projection
+    jobs.append(dict(frame=0, proj=jobs[0]["proj"], proj_mask=jobs[0]["proj_mask"], px=2.3, py=1.1, threshold=0.98, stride=3))
+    jobs.append(dict(frame=0, proj=jobs[1]["proj"], proj_mask=jobs[1]["proj_mask"], px=w - 1.5, py=h - 2.0, threshold=0.5, stride=3))
+    jobs.append(dict(frame=0, proj=jobs[2]["proj"], proj_mask=jobs[2]["proj_mask"], px=-400.0, py=50.0, threshold=0.98, stride=3))
+    jobs.append(dict(frame=0, proj=None, proj_mask=None, px=10.0, py=10.0, threshold=0.98, stride=3))
+    pyr = api.ImagePyramid(ctx, f1, subs)
+    try:
+        got = api.track_batch(ctx, pyr, jobs)
+        levels = oracle.pyramid(f1, subs)
+        nfound = 0
+        for j, g in zip(jobs, got):
+            assert g["status"] == 0
+            if j["proj"] is None:
+                assert (g["x"], g["y"], g["response"]) == (-1, -1, -1.0)
+                continue
+            r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+            assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"])
+            assert _same_float(g["response"], r["response"])
+            assert _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+            if "truth" in j and g["response"] > j["threshold"]:
+                nfound += (g["x"], g["y"]) == j["truth"]
+        assert nfound >= min_found      # sanity: the synthetic sequence is actually tracked
+    finally:
+        pyr.close()
+
+
+def _kp_set(a):
+    return [tuple(r) for r in np.asarray(a).tolist()]
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (641, 479), (1920, 1080), (7, 7), (6, 40), (64, 9)])
+def test_fast_matches_oracle(ctx, oracle, w, h):
+    frames = np.stack([synth.frame(w, h, 21 + i, (17 * i, 9 * i)) for i in range(2)])
+    for thr, nms in [(10, True), (40, True), (0, True), (300, True), (20, False)]:
+        got, counts, rc = api.fast(ctx, frames, thr, nms)
+        assert rc == 0
+        for f in range(2):
+            ref = oracle.fast(frames[f], thr, nms)
+            assert counts[f] == len(ref)
+            assert _kp_set(got[f]) == _kp_set(ref), (w, h, thr, nms, f)   # same set AND same (row-major) order
+
+
+def test_fast_capacity_is_reported(ctx, oracle):
+    frame = synth.frame(320, 240, 3)
+    ref = oracle.fast(frame, 10, True)
+    assert len(ref) > 50
+    got, counts, rc = api.fast(ctx, frame, 10, True, cap=32)
+    assert rc == api.capi.ECAP and counts[0] == len(ref) and len(got[0]) == 32
+
+
+def test_get_sorted_keypoints_matches_oracle(ctx, oracle):
+    for (w, h, nmin, f0) in [(640, 480, 100, 10.0), (320, 240, 100, 200.0), (320, 240, 5, 10.0), (64, 64, 100000, 10.0)]:
+        im = synth.frame(w, h, 33)
+        ref, fref = oracle.get_sorted_keypoints(im, nmin, f0)
+        got, fgot = api.get_sorted_keypoints(ctx, im, nmin, f0)
+        assert fgot == fref
+        assert _kp_set(got) == _kp_set(ref)
+    # an image without corners terminates (the reference would not) and returns nothing
+    got, fgot = api.get_sorted_keypoints(ctx, np.full((40, 40), 9, np.uint8), 10, 10.0)
+    assert len(got) == 0
