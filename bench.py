@@ -164,7 +164,8 @@ def main():
     d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)
     d_blob = torch.from_numpy(blob).to(dev)
     d_out = torch.zeros(njobs * TRACK_RES_DT.itemsize, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by the kernels and the events
+    torch.cuda.set_stream(stream)
     ctx = api.Context(local_rank, stream=stream.cuda_stream)
     pyr = api.ImagePyramid(ctx, None, SUBS, device_ptr=d_frames.data_ptr(), pitch=W, frame_stride=W * H,
                            shape=(nframes, H, W))

@@ -1,5 +1,6 @@
 // Context, error reporting, device-memory helpers and host-side resize tap tables.
 #include <cmath>
+#include <cstdlib>
 
 #include "slam_internal.h"
 
@@ -42,6 +43,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
         return slam_set_error(nullptr, SLAM_HIP_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     c->stream = c->own_stream;
+    const char* fd = getenv("SLAM_HIP_FORCE_DIRECT");
+    c->force_direct = (fd && fd[0] == '1') ? 1 : 0;
     *out = c;
     return SLAM_HIP_OK;
 }

@@ -6,31 +6,22 @@
 #include <cfloat>
 #include <climits>
 
-#include "match_common.h"
+#include "match_fast.h"
 
 using namespace slamdev;
 
 namespace {
 
-struct CoreOut { int x, y; float response, dx, dy; };
+constexpr int CORE_SHARED_BYTES = 256;
+constexpr int TRACK_TABLE_BYTES = 4 * 4 * SLAM_MAX_TMPL;
+static_assert(sizeof(CoreShared) <= CORE_SHARED_BYTES, "CoreShared carve-out");
 
-struct CoreShared {
-    unsigned long long red64[SLAM_WG / 64];
-    float bestv[SLAM_WG / 64];
-    int besti[SLAM_WG / 64];
-    unsigned long long spfull;
-    float nb[4];        // neighbour scores for the sub-pixel fit
-    int nbok[4];
-    CoreOut out;
-};
-
-// Reference-exact search of one job by direct evaluation: every score cell the reference visits is
-// computed by one lane looping over the template pixels.
-__device__ CoreOut match_core_direct(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm) {
+// Direct evaluation of every score cell the reference visits: one lane per cell, looping over the
+// template pixels.  Used for templates wider than the tiled core supports and as an in-GPU
+// cross-check of the tiled core (SLAM_HIP_FORCE_DIRECT=1).
+__device__ void direct_cells(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm, Best& b) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-    // |patch0|^2 over the whole template (matching.cpp:63,109; template norm of matchTemplate)
-    {
+    {   // |patch0|^2 over the whole template (matching.cpp:63,109; template norm of matchTemplate)
         unsigned long long sp = 0;
         const int n = t.tw * t.th;
         for (int i = tid; i < n; i += SLAM_WG) {
@@ -46,8 +37,6 @@ __device__ CoreOut match_core_direct(const Geo& g, const Tmpl& t, float* scores,
         __syncthreads();
     }
     const unsigned long long spfull = sm.spfull;
-
-    Best b = {-FLT_MAX, INT_MAX};
     const int ncell = g.aw * g.ah;
     for (int c = tid; c < ncell; c += SLAM_WG) {
         const int x = c % g.aw, y = c / g.aw;
@@ -67,6 +56,22 @@ __device__ CoreOut match_core_direct(const Geo& g, const Tmpl& t, float* scores,
         if (scores) scores[c] = sc;
         best_update(b, sc, c);
     }
+}
+
+// SLAM::matchFeatureInArea for one job by the whole workgroup: score cells (tiled packed-u8 core or
+// direct evaluation), cv::minMaxLoc argmax, sub-pixel fit.  Returns the result in every lane.
+__device__ CoreOut match_core(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm,
+                              unsigned char* lds, bool force_direct) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    Best b = {-FLT_MAX, INT_MAX};
+    if (!force_direct && fast_supported(g)) {
+        if (fast_cost(g, 8) < fast_cost(g, 4)) fast_blocks<8>(g, t, scores, sm, lds, b);
+        else fast_blocks<4>(g, t, scores, sm, lds, b);
+    } else {
+        direct_cells(g, t, scores, sm, b);
+    }
+    __syncthreads();
+    const unsigned long long spfull = sm.spfull;
     b = best_wave(b);
     if (lane == 0) { sm.bestv[wid] = b.v; sm.besti[wid] = b.idx; }
     __syncthreads();
@@ -139,12 +144,14 @@ __device__ __forceinline__ bool span_ok(long long off, long long len, unsigned l
     return off >= 0 && len >= 0 && (unsigned long long)off <= total && (unsigned long long)len <= total - (unsigned long long)off;
 }
 
-__global__ __launch_bounds__(SLAM_WG) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
+__global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes, float* scores,
                                                         unsigned long long scores_len,
-                                                        slam_match_result* __restrict__ out) {
-    __shared__ CoreShared sm;
+                                                        slam_match_result* __restrict__ out, int force_direct) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    CoreShared& sm = *reinterpret_cast<CoreShared*>(dyn_lds);
+    unsigned char* lds = dyn_lds + CORE_SHARED_BYTES;
     const int j = blockIdx.x;
     if (j >= njobs) return;
     const slam_match_job job = jobs[j];
@@ -185,17 +192,21 @@ __global__ __launch_bounds__(SLAM_WG) void match_kernel(slam_pyr_dev pyr, const 
     t.mask = job.pmask_off != -1 ? blob + job.pmask_off : nullptr;
     t.srcw = job.pw; t.srch = job.ph; t.tw = job.pw; t.th = job.ph; t.resized = false;
     t.xofs = nullptr; t.xcoef = nullptr; t.yofs = nullptr; t.ycoef = nullptr;
-    const CoreOut o = match_core_direct(g, t, sc, sm);
+    const CoreOut o = match_core(g, t, sc, sm, lds, force_direct != 0);
     if (threadIdx.x == 0) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
 }
 
-__global__ __launch_bounds__(SLAM_WG) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+__global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
-                                                        slam_track_result* __restrict__ out) {
-    __shared__ CoreShared sm;
-    __shared__ int s_xofs[SLAM_MAX_TMPL], s_yofs[SLAM_MAX_TMPL];
-    __shared__ unsigned s_xcoef[SLAM_MAX_TMPL], s_ycoef[SLAM_MAX_TMPL];
+                                                        slam_track_result* __restrict__ out, int force_direct) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    CoreShared& sm = *reinterpret_cast<CoreShared*>(dyn_lds);
+    int* s_xofs = reinterpret_cast<int*>(dyn_lds + CORE_SHARED_BYTES);
+    int* s_yofs = s_xofs + SLAM_MAX_TMPL;
+    unsigned* s_xcoef = reinterpret_cast<unsigned*>(s_yofs + SLAM_MAX_TMPL);
+    unsigned* s_ycoef = s_xcoef + SLAM_MAX_TMPL;
+    unsigned char* lds = dyn_lds + CORE_SHARED_BYTES + TRACK_TABLE_BYTES;
     const int j = blockIdx.x;
     if (j >= njobs) return;
     const slam_track_job job = jobs[j];
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(SLAM_WG) void track_kernel(slam_pyr_dev pyr, const 
         sdx = 0.f; sdy = 0.f;
         if (g.reject) { response = -1.f; }       // matching.cpp:26-30
         else {
-            const CoreOut o = match_core_direct(g, t, nullptr, sm);
+            const CoreOut o = match_core(g, t, nullptr, sm, lds, force_direct != 0);
             mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
         }
         tx = __fmul_rn((float)mx, sub);          // feature.cpp:150
@@ -302,8 +313,9 @@ extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), 0, ctx->stream, pyr->dev, d_jobs, njobs,
-                       d_blob, (unsigned long long)blob_bytes, d_scores, (unsigned long long)scores_len, d_out);
+    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), CORE_SHARED_BYTES + FAST_LDS_BYTES, ctx->stream,
+                       pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
+                       (unsigned long long)scores_len, d_out, ctx->force_direct);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }
@@ -401,8 +413,9 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), 0, ctx->stream, pyr->dev, d_jobs, njobs,
-                       d_blob, (unsigned long long)blob_bytes, d_out);
+    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), CORE_SHARED_BYTES + TRACK_TABLE_BYTES + FAST_LDS_BYTES,
+                       ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
+                       ctx->force_direct);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }

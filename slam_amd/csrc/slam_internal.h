@@ -17,6 +17,7 @@ struct slam_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     char err[512] = {0};
+    int force_direct = 0;   // SLAM_HIP_FORCE_DIRECT=1: search by direct evaluation (cross-check of the tiled core)
     // growable device staging buffers used by the host-table entry points
     void* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
