@@ -1,4 +1,4 @@
-// Template search kernels: one workgroup per job.
+// Template search kernels: one wavefront (workgroup of 64 lanes) per job.
 //   match_kernel  = SLAM::matchFeatureInArea (matching.cpp:9-228) for a table of jobs
 //   track_kernel  = the level loop of SLAM::Feature::track (feature.cpp:117-172), walking the
 //                   pyramid levels of one feature inside one workgroup (each level's window depends
@@ -12,33 +12,26 @@ using namespace slamdev;
 
 namespace {
 
-constexpr int CORE_SHARED_BYTES = 256;
-constexpr int TRACK_TABLE_BYTES = 4 * 4 * SLAM_MAX_TMPL;
-static_assert(sizeof(CoreShared) <= CORE_SHARED_BYTES, "CoreShared carve-out");
+static_assert(SLAM_WG == 64, "the search kernels assume one wavefront per workgroup");
 
 // Direct evaluation of every score cell the reference visits: one lane per cell, looping over the
 // template pixels.  Used for templates wider than the tiled core supports and as an in-GPU
 // cross-check of the tiled core (SLAM_HIP_FORCE_DIRECT=1).
-__device__ void direct_cells(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm, Best& b) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+__device__ __forceinline__ void direct_cells(const Geo& g, const Tmpl& t, float* scores, unsigned long long& spfull, Best& b) {
+    const int lane = threadIdx.x;
     {   // |patch0|^2 over the whole template (matching.cpp:63,109; template norm of matchTemplate)
         unsigned long long sp = 0;
         const int n = t.tw * t.th;
-        for (int i = tid; i < n; i += SLAM_WG) {
+        for (int i = lane; i < n; i += SLAM_WG) {
             unsigned p, m;
             tmpl_fetch(t, i / t.tw, i % t.tw, p, m);
             p *= m;
             sp += p * p;
         }
-        sp = wave_sum_u64(sp);
-        if (lane == 0) sm.red64[wid] = sp;
-        __syncthreads();
-        if (tid == 0) sm.spfull = sm.red64[0] + sm.red64[1] + sm.red64[2] + sm.red64[3];
-        __syncthreads();
+        spfull = wave_sum_u64(sp);
     }
-    const unsigned long long spfull = sm.spfull;
     const int ncell = g.aw * g.ah;
-    for (int c = tid; c < ncell; c += SLAM_WG) {
+    for (int c = lane; c < ncell; c += SLAM_WG) {
         const int x = c % g.aw, y = c / g.aw;
         const int kind = classify_cell(g, x, y);
         float sc = -1.f;                                   // matching.cpp:53
@@ -58,86 +51,89 @@ __device__ void direct_cells(const Geo& g, const Tmpl& t, float* scores, CoreSha
     }
 }
 
-// SLAM::matchFeatureInArea for one job by the whole workgroup: score cells (tiled packed-u8 core or
-// direct evaluation), cv::minMaxLoc argmax, sub-pixel fit.  Returns the result in every lane.
-__device__ CoreOut match_core(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm,
-                              unsigned char* lds, bool force_direct) {
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    Best b = {-FLT_MAX, INT_MAX};
-    if (!force_direct && fast_supported(g)) {
-        if (fast_cost(g, 8) < fast_cost(g, 4)) fast_blocks<8>(g, t, scores, sm, lds, b);
-        else fast_blocks<4>(g, t, scores, sm, lds, b);
-    } else {
-        direct_cells(g, t, scores, sm, b);
+// Score-map value of cell (nx, ny) recomputed by the 64 lanes together (-1 for unvisited cells).
+__device__ __forceinline__ float cell_score_coop(const Geo& g, const Tmpl& t, int nx, int ny, unsigned long long spfull) {
+    const int kind = classify_cell(g, nx, ny);
+    if (kind == CELL_NONE) return -1.f;
+    int dl = 0, dr = 0, dt = 0, db = 0;
+    if (kind == CELL_F32_CROP) {
+        dl = max(0, -g.x0 - nx); dr = max(0, g.x0 + nx + g.pw - g.w);
+        dt = max(0, -g.y0 - ny); db = max(0, g.y0 + ny + g.ph - g.h);
     }
-    __syncthreads();
-    const unsigned long long spfull = sm.spfull;
-    b = best_wave(b);
-    if (lane == 0) { sm.bestv[wid] = b.v; sm.besti[wid] = b.idx; }
-    __syncthreads();
-    Best bb = {sm.bestv[0], sm.besti[0]};
-#pragma unroll
-    for (int k = 1; k < SLAM_WG / 64; k++) {
-        const float ov = sm.bestv[k]; const int oi = sm.besti[k];
-        if (ov > bb.v || (ov == bb.v && oi < bb.idx)) { bb.v = ov; bb.idx = oi; }
-    }
+    Sums s = cell_sums_partial(g, t, g.x0 + nx, g.y0 + ny, dl, g.pw - dr, dt, g.ph - db, (int)threadIdx.x, SLAM_WG);
+    s.cc = wave_sum_u64(s.cc); s.si = wave_sum_u64(s.si); s.sp = wave_sum_u64(s.sp);
+    return (kind == CELL_MT) ? score_mt(s.cc, s.si, spfull)
+         : (kind == CELL_F32_FULL) ? score_f32(s.cc, s.si, spfull)
+                                   : score_f32(s.cc, s.si, s.sp);
+}
 
-    // sub-pixel fit: the four neighbours of the peak, one wavefront each
-    const bool found = bb.idx != INT_MAX;
-    const int lx = found ? bb.idx % g.aw : -1, ly = found ? bb.idx / g.aw : -1;
-    {
-        const int nx = lx + (wid == 0 ? -1 : wid == 1 ? 1 : 0);
-        const int ny = ly + (wid == 2 ? -1 : wid == 3 ? 1 : 0);
-        const bool inside = found && nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
-        float sc = -1.f;
-        if (inside) {
-            const int kind = classify_cell(g, nx, ny);
-            if (kind != CELL_NONE) {
-                int dl = 0, dr = 0, dt = 0, db = 0;
-                if (kind == CELL_F32_CROP) {
-                    dl = max(0, -g.x0 - nx); dr = max(0, g.x0 + nx + g.pw - g.w);
-                    dt = max(0, -g.y0 - ny); db = max(0, g.y0 + ny + g.ph - g.h);
-                }
-                Sums s = cell_sums_partial(g, t, g.x0 + nx, g.y0 + ny, dl, g.pw - dr, dt, g.ph - db, lane, 64);
-                s.cc = wave_sum_u64(s.cc); s.si = wave_sum_u64(s.si); s.sp = wave_sum_u64(s.sp);
-                sc = (kind == CELL_MT) ? score_mt(s.cc, s.si, spfull)
-                   : (kind == CELL_F32_FULL) ? score_f32(s.cc, s.si, spfull)
-                                             : score_f32(s.cc, s.si, s.sp);
-            }
-        }
-        if (lane == 0) { sm.nb[wid] = sc; sm.nbok[wid] = inside ? 1 : 0; }
+struct CoreState {
+    Best best;                  // wave-uniform after match_core
+    unsigned long long spfull;
+    FastState fs;
+    bool used_fast;
+};
+
+// SLAM::matchFeatureInArea for one job: score cells (tiled packed-u8 core or direct evaluation) and
+// the cv::minMaxLoc argmax.  The result is uniform over the wavefront.
+__device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, bool force_direct, CoreState& st) {
+    Best b = {-FLT_MAX, INT_MAX};
+    st.spfull = 0;
+    st.fs.single_block = false;
+    st.used_fast = !force_direct && fast_supported(g);
+    if (st.used_fast) {
+        if (fast_cost(g, 8) < fast_cost(g, 4)) fast_blocks<8>(g, t, scores, lds, st.spfull, b, st.fs);
+        else fast_blocks<4>(g, t, scores, lds, st.spfull, b, st.fs);
+    } else {
+        direct_cells(g, t, scores, st.spfull, b);
     }
-    __syncthreads();
-    if (tid == 0) {
-        CoreOut o;
-        o.dx = 0.f; o.dy = 0.f;
-        if (!found) {            // nothing compared greater than -FLT_MAX: every cell is NaN
-            o.x = -1 + g.ax; o.y = -1 + g.ay; o.response = 0.f;
-        } else {
-            o.x = lx + g.ax; o.y = ly + g.ay; o.response = bb.v;
-            const float s = bb.v;
-            const float sl = sm.nb[0], sr = sm.nb[1], su = sm.nb[2], sd = sm.nb[3];
-            if (sm.nbok[0] && sm.nbok[1] && sl != -1.f && sr != -1.f && sl == sl && sr == sr) {
-                const float d2 = __fsub_rn(__fadd_rn(sl, sr), __fmul_rn(2.0f, s));
-                if (d2 < 0.f) {
-                    const float q = __fdiv_rn(__fsub_rn(sl, sr), __fmul_rn(2.0f, d2));
-                    o.dx = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
-                }
-            }
-            if (sm.nbok[2] && sm.nbok[3] && su != -1.f && sd != -1.f && su == su && sd == sd) {
-                const float d2 = __fsub_rn(__fadd_rn(su, sd), __fmul_rn(2.0f, s));
-                if (d2 < 0.f) {
-                    const float q = __fdiv_rn(__fsub_rn(su, sd), __fmul_rn(2.0f, d2));
-                    o.dy = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
-                }
-            }
-        }
-        sm.out = o;
+    b = best_wave(b);
+    st.best = b;
+    CoreOut o;
+    o.dx = 0.f; o.dy = 0.f;
+    if (b.idx == INT_MAX) {      // nothing compared greater than -FLT_MAX: every cell is NaN
+        o.x = -1 + g.ax; o.y = -1 + g.ay; o.response = 0.f;
+    } else {
+        o.x = b.idx % g.aw + g.ax; o.y = b.idx / g.aw + g.ay; o.response = b.v;
     }
-    __syncthreads();
-    const CoreOut r = sm.out;
-    __syncthreads();
-    return r;
+    return o;
+}
+
+// Sub-pixel offset of the peak: parabola through the two horizontal / vertical neighbours of the
+// argmax cell (not in the reference).  Neighbour scores come from the block accumulators when the
+// whole map was one block of the tiled core, otherwise they are recomputed.
+__device__ __forceinline__ void subpixel(const Geo& g, const Tmpl& t, const lds_u8* lds, const CoreState& st, CoreOut& o) {
+    o.dx = 0.f; o.dy = 0.f;
+    if (st.best.idx == INT_MAX) return;
+    const int lx = st.best.idx % g.aw, ly = st.best.idx / g.aw;
+    const float s = st.best.v;
+    float nb[4];
+    bool ok[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const int nx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0);
+        const int ny = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
+        ok[n] = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
+        nb[n] = -1.f;
+        if (ok[n]) {
+            if (st.used_fast && st.fs.single_block) nb[n] = fast_cell_score(g, lds, st.fs, nx, ny, st.spfull);
+            else nb[n] = cell_score_coop(g, t, nx, ny, st.spfull);
+        }
+    }
+    if (ok[0] && ok[1] && nb[0] != -1.f && nb[1] != -1.f && nb[0] == nb[0] && nb[1] == nb[1]) {
+        const float d2 = __fsub_rn(__fadd_rn(nb[0], nb[1]), __fmul_rn(2.0f, s));
+        if (d2 < 0.f) {
+            const float q = __fdiv_rn(__fsub_rn(nb[0], nb[1]), __fmul_rn(2.0f, d2));
+            o.dx = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
+        }
+    }
+    if (ok[2] && ok[3] && nb[2] != -1.f && nb[3] != -1.f && nb[2] == nb[2] && nb[3] == nb[3]) {
+        const float d2 = __fsub_rn(__fadd_rn(nb[2], nb[3]), __fmul_rn(2.0f, s));
+        if (d2 < 0.f) {
+            const float q = __fdiv_rn(__fsub_rn(nb[2], nb[3]), __fmul_rn(2.0f, d2));
+            o.dy = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
+        }
+    }
 }
 
 __device__ __forceinline__ bool span_ok(long long off, long long len, unsigned long long total) {
@@ -150,8 +146,7 @@ __global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, con
                                                         unsigned long long scores_len,
                                                         slam_match_result* __restrict__ out, int force_direct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    CoreShared& sm = *reinterpret_cast<CoreShared*>(dyn_lds);
-    unsigned char* lds = dyn_lds + CORE_SHARED_BYTES;
+    lds_u8* lds = (lds_u8*)dyn_lds;
     const int j = blockIdx.x;
     if (j >= njobs) return;
     const slam_match_job job = jobs[j];
@@ -191,8 +186,10 @@ __global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, con
     t.patch = blob + job.patch_off;
     t.mask = job.pmask_off != -1 ? blob + job.pmask_off : nullptr;
     t.srcw = job.pw; t.srch = job.ph; t.tw = job.pw; t.th = job.ph; t.resized = false;
-    t.xofs = nullptr; t.xcoef = nullptr; t.yofs = nullptr; t.ycoef = nullptr;
-    const CoreOut o = match_core(g, t, sc, sm, lds, force_direct != 0);
+    t.scale_x = 1.0; t.scale_y = 1.0;
+    CoreState st;
+    CoreOut o = match_core(g, t, sc, lds, force_direct != 0, st);
+    subpixel(g, t, lds, st, o);
     if (threadIdx.x == 0) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
 }
 
@@ -201,12 +198,7 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
                                                         unsigned long long blob_bytes,
                                                         slam_track_result* __restrict__ out, int force_direct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    CoreShared& sm = *reinterpret_cast<CoreShared*>(dyn_lds);
-    int* s_xofs = reinterpret_cast<int*>(dyn_lds + CORE_SHARED_BYTES);
-    int* s_yofs = s_xofs + SLAM_MAX_TMPL;
-    unsigned* s_xcoef = reinterpret_cast<unsigned*>(s_yofs + SLAM_MAX_TMPL);
-    unsigned* s_ycoef = s_xcoef + SLAM_MAX_TMPL;
-    unsigned char* lds = dyn_lds + CORE_SHARED_BYTES + TRACK_TABLE_BYTES;
+    lds_u8* lds = (lds_u8*)dyn_lds;
     const int j = blockIdx.x;
     if (j >= njobs) return;
     const slam_track_job job = jobs[j];
@@ -227,7 +219,7 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
     Tmpl t;
     t.patch = blob + job.proj_off; t.mask = blob + job.mask_off;
     t.srcw = job.projw; t.srch = job.projh;
-    t.xofs = s_xofs; t.xcoef = s_xcoef; t.yofs = s_yofs; t.ycoef = s_ycoef;
+    t.scale_x = 1.0; t.scale_y = 1.0;
 
     float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
     float response = 0.f, sdx = 0.f, sdy = 0.f;
@@ -248,10 +240,8 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
             t.th = (int)__fdiv_rn((float)job.projh, sub);
             t.resized = true;
             if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
-            __syncthreads();                     // the previous level no longer reads the tables
-            for (int d = tid; d < t.tw; d += SLAM_WG) resize_tap(d, job.projw, t.tw, true, s_xofs[d], s_xcoef[d]);
-            for (int d = tid; d < t.th; d += SLAM_WG) resize_tap(d, job.projh, t.th, false, s_yofs[d], s_ycoef[d]);
-            __syncthreads();
+            t.scale_x = resize_scale(job.projw, t.tw);
+            t.scale_y = resize_scale(job.projh, t.th);
         }
         float searchRad;
         if (i == pyr.nlev - 1) {
@@ -268,14 +258,18 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
                                nullptr, (i == 0) ? 1 : job.stride, true, false);   // feature.cpp:147-149
         int mx = 0, my = 0;
         sdx = 0.f; sdy = 0.f;
+        levels_run++;
         if (g.reject) { response = -1.f; }       // matching.cpp:26-30
         else {
-            const CoreOut o = match_core(g, t, nullptr, sm, lds, force_direct != 0);
-            mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
+            CoreState st;
+            CoreOut o = match_core(g, t, nullptr, lds, force_direct != 0, st);
+            mx = o.x; my = o.y; response = o.response;
+            // feature.cpp:151-152; the sub-pixel fit is only reported for the last level run
+            const bool last = (i == 0) || ((double)response < __dmul_rn(0.67, (double)job.threshold));
+            if (last) { subpixel(g, t, lds, st, o); sdx = o.dx; sdy = o.dy; }
         }
         tx = __fmul_rn((float)mx, sub);          // feature.cpp:150
         ty = __fmul_rn((float)my, sub);
-        levels_run++;
         if ((double)response < __dmul_rn(0.67, (double)job.threshold)) break;   // feature.cpp:151-152
     }
     if (tid == 0) {
@@ -313,7 +307,7 @@ extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), CORE_SHARED_BYTES + FAST_LDS_BYTES, ctx->stream,
+    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), FAST_LDS_BYTES, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
                        (unsigned long long)scores_len, d_out, ctx->force_direct);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
@@ -413,7 +407,7 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), CORE_SHARED_BYTES + TRACK_TABLE_BYTES + FAST_LDS_BYTES,
+    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), FAST_LDS_BYTES,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
                        ctx->force_direct);
     SLAM_HIP_CHECK(ctx, hipGetLastError());

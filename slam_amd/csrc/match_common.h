@@ -6,8 +6,8 @@
 
 #include "slam_internal.h"
 
-#define SLAM_WG 256          // threads per workgroup of the search kernels (4 wavefronts)
-#define SLAM_MAX_TMPL 512    // max template width/height handled by the on-device resize tables
+#define SLAM_WG 64           // one wavefront per job: no cross-wave synchronisation, many jobs per CU
+#define SLAM_MAX_TMPL 512    // max template width/height of a track job (the reference caps projections at 500)
 
 namespace slamdev {
 
@@ -92,19 +92,22 @@ __device__ __forceinline__ int classify_cell(const Geo& g, int x, int y) {
     const bool am = !g.amask || g.amask[(long long)y * g.ampitch + x] != 0;
     if (interior) {
         if (g.masked) {
-            if (((x - g.xl0) % g.stride) != 0 || ((y - g.yl0) % g.stride) != 0) return CELL_NONE;
+            if (g.stride != 1 && (((x - g.xl0) % g.stride) != 0 || ((y - g.yl0) % g.stride) != 0)) return CELL_NONE;
             return am ? CELL_F32_FULL : CELL_NONE;
         }
         if (g.exact && !am) return CELL_NONE;
         return CELL_MT;
     }
-    if ((x % g.stride) != 0) return CELL_NONE;
-    bool on;
-    if (inx && g.yf < g.yl1)   // this column's walk hits the interior block at yf and jumps to yl1
-        on = (y < g.yl0) ? ((y % g.stride) == 0) : ((y >= g.yl1) && (((y - g.yl1) % g.stride) == 0));
-    else
-        on = (y % g.stride) == 0;
-    if (!on || !am) return CELL_NONE;
+    if (g.stride != 1) {
+        if ((x % g.stride) != 0) return CELL_NONE;
+        bool on;
+        if (inx && g.yf < g.yl1)   // this column's walk hits the interior block at yf and jumps to yl1
+            on = (y < g.yl0) ? ((y % g.stride) == 0) : ((y >= g.yl1) && (((y - g.yl1) % g.stride) == 0));
+        else
+            on = (y % g.stride) == 0;
+        if (!on) return CELL_NONE;
+    }
+    if (!am) return CELL_NONE;
     const int dl = max(0, -g.x0 - x), dr = max(0, g.x0 + x + g.pw - g.w);
     const int dt = max(0, -g.y0 - y), db = max(0, g.y0 + y + g.ph - g.h);
     return (dt + db < g.ph && dl + dr < g.pw) ? CELL_F32_CROP : CELL_NONE;
@@ -119,13 +122,33 @@ struct Tmpl {
     int srcw, srch;
     int tw, th;               // size at this level
     bool resized;
-    const int* xofs; const unsigned* xcoef;   // LDS tables when resized
-    const int* yofs; const unsigned* ycoef;
+    double scale_x, scale_y;  // cv::resize's scale = 1 / ((double)dsize / ssize), when resized
 };
 
-__device__ __forceinline__ int resize_px(const uint8_t* S, int sw, int sh, int sx, unsigned xc, int sy, unsigned yc, bool binarize) {
-    const int a0 = (int)(short)(xc & 0xffff), a1 = (int)(short)(xc >> 16);
-    const int b0 = (int)(short)(yc & 0xffff), b1 = (int)(short)(yc >> 16);
+// cv::resize's scale factor for one axis
+__device__ __forceinline__ double resize_scale(int ssize, int dsize) {
+    return __ddiv_rn(1.0, __ddiv_rn((double)dsize, (double)ssize));
+}
+
+// One tap of cv::resize(INTER_LINEAR) for destination index d, with the same double/float steps
+// as OpenCV's resize(): f = (float)((d+0.5)*scale - 0.5); s = floor(f); f -= s; weights =
+// round-half-even((1-f)*2048), (f*2048) saturated to int16.  Columns reset the fraction at the
+// image edges (clamp_fraction); rows keep it and clamp the row index when it is used.
+__device__ __forceinline__ void resize_tap(int d, double scale, int ssize, bool clamp_fraction, int& ofs, int& c0, int& c1) {
+    const double t = __dmul_rn((double)d + 0.5, scale);
+    float f = (float)__dadd_rn(t, -0.5);
+    int s = (int)floorf(f);
+    f = __fsub_rn(f, (float)s);
+    if (clamp_fraction) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    }
+    c0 = min(max(__float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f)), -32768), 32767);
+    c1 = min(max(__float2int_rn(__fmul_rn(f, 2048.f)), -32768), 32767);
+    ofs = s;
+}
+
+__device__ __forceinline__ int resize_px(const uint8_t* S, int sw, int sh, int sx, int a0, int a1, int sy, int b0, int b1, bool binarize) {
     const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
     const int sx1 = min(sx + 1, sw - 1);
     int p00 = S[(long long)r0 * sw + sx], p01 = S[(long long)r0 * sw + sx1];
@@ -142,33 +165,12 @@ __device__ __forceinline__ void tmpl_fetch(const Tmpl& t, int u, int v, unsigned
         p = t.patch[(long long)u * t.srcw + v];
         m = t.mask ? (t.mask[(long long)u * t.srcw + v] != 0) : 1u;
     } else {
-        const int sx = t.xofs[v], sy = t.yofs[u];
-        const unsigned xc = t.xcoef[v], yc = t.ycoef[u];
-        p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, xc, sy, yc, false);
-        m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, xc, sy, yc, true) != 0) : 1u;
+        int sx, a0, a1, sy, b0, b1;
+        resize_tap(v, t.scale_x, t.srcw, true, sx, a0, a1);
+        resize_tap(u, t.scale_y, t.srch, false, sy, b0, b1);
+        p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, false);
+        m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, true) != 0) : 1u;
     }
-}
-
-// One entry of cv::resize's tap tables, computed on the device with the same double/float steps
-// as OpenCV's resize(): scale = 1/((double)dsize/ssize); f = (float)((d+0.5)*scale - 0.5);
-// s = floor(f); f -= s; weights = round-half-even((1-f)*2048), (f*2048).
-__device__ __forceinline__ void resize_tap(int d, int ssize, int dsize, bool clamp_fraction, int& ofs, unsigned& coef) {
-    const double inv_scale = __ddiv_rn((double)dsize, (double)ssize);
-    const double scale = __ddiv_rn(1.0, inv_scale);
-    const double t = __dmul_rn((double)d + 0.5, scale);
-    float f = (float)__dadd_rn(t, -0.5);
-    int s = (int)floorf(f);
-    f = __fsub_rn(f, (float)s);
-    if (clamp_fraction) {
-        if (s < 0) { f = 0.f; s = 0; }
-        if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
-    }
-    int c0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
-    int c1 = __float2int_rn(__fmul_rn(f, 2048.f));
-    c0 = min(max(c0, -32768), 32767);
-    c1 = min(max(c1, -32768), 32767);
-    ofs = s;
-    coef = (unsigned)(unsigned short)(short)c0 | ((unsigned)(unsigned short)(short)c1 << 16);
 }
 
 // ---- sums over one cell ---------------------------------------------------------------------

@@ -1,66 +1,69 @@
-// LDS-tiled packed-u8 search core (one workgroup of 256 lanes per job).
+// LDS-tiled packed-u8 search core: one wavefront (64 lanes) per job.
 //
 // Data layout in LDS (dynamic, FAST_LDS_BYTES):
-//   acc   : per-cell partial sums (CC, SI, SPcrop) as u32, used only when a cell's template rows
-//           are split over several lanes
-//   tmpl  : the current chunk of template rows, per 4-pixel group {P0 dword, mask dword}:
-//           P0 = patch*mask packed 4 pixels/dword, mask = 0xFF per kept pixel (0 beyond pw)
-//   tile  : image rows under all cells of the current block, zero outside the image, 4-byte
-//           aligned to IMAGE columns so that rows are fetched as dwords when the image is aligned
+//   acc   : per-cell sums {CC, SI[, SPcrop]} of the current block (u32, or u64 for templates of
+//           more than 66051 pixels), accumulated with LDS atomics
+//   tmpl  : the current chunk of template rows, one 8-byte entry per 4-pixel group:
+//           low dword  P0   = patch*mask, 4 pixels
+//           high dword mask = 0xFF per kept pixel (0 where masked out or beyond the patch width)
+//   tile  : image rows under all cells of the current block, zero outside the image; tile column 0
+//           is a multiple of 4 in IMAGE columns so rows are fetched as aligned dwords
 //   vtile : 0xFF where the tile pixel is inside the image (only for blocks with cropped cells)
 //
 // Work split: the block's cells are cut into strips of J (4 or 8) consecutive cells of one row; a
-// lane owns one strip and one slice of the chunk's template rows.  Per 4-pixel group it forms,
-// for each of its J cells, the cell's 4 image pixels with one v_perm_b32 (byte alignment and the
-// patch mask in one selector) and feeds two v_dot4_u32_u8 (CC += <Im,P0>, SI += <Im,Im>); blocks
-// with cropped cells add SPcrop += <P0 & valid, P0>.  All sums are exact integers.
+// task is one strip x one slice of the chunk's template rows, and the 64 lanes walk the task list.
+// Per 4-pixel group a lane forms, for each of its J cells, the cell's 4 image pixels with one
+// v_perm_b32 (byte alignment and patch mask folded into one selector) and feeds two v_dot4_u32_u8
+// (CC += <Im,P0>, SI += <Im,Im>); blocks with cropped cells add SPcrop += <P0 & valid, P0>.
+// Every sum is an exact integer, so the scores are bit-identical to a scalar evaluation.
 #pragma once
 
 #include "match_common.h"
 
-#define FAST_LDS_BYTES (24 * 1024)
-#define FAST_ACC_BYTES (6 * 1024)
-#define FAST_TMPL_BYTES (6 * 1024)
-#define FAST_TILE_BYTES (12 * 1024)
-#define FAST_MAX_G 256        // template width up to 1024 pixels
+#define FAST_ACC_BYTES (8 * 1024)
+#define FAST_TMPL_BYTES (3 * 1024)
+#define FAST_TILE_BYTES (5 * 1024)
+#define FAST_LDS_BYTES (FAST_ACC_BYTES + FAST_TMPL_BYTES + FAST_TILE_BYTES)
+#define FAST_MAX_G 96         // template width up to 384 pixels; wider ones use direct evaluation
 
 namespace slamdev {
 
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
 struct CoreOut { int x, y; float response, dx, dy; };
 
-struct CoreShared {
-    unsigned long long red64[SLAM_WG / 64];
-    float bestv[SLAM_WG / 64];
-    int besti[SLAM_WG / 64];
-    unsigned long long spfull;
-    float nb[4];
-    int nbok[4];
-    CoreOut out;
+// What the tiled core leaves behind for the sub-pixel fit when the whole score map was one block.
+struct FastState {
+    bool single_block;
+    bool border, big;
+    int J, xb, yb, strips, bh;
 };
 
 __device__ __forceinline__ unsigned bfi32(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
 
-// Accumulate template rows [ub, ue) (chunk-relative) for the J cells of one strip.
-// tile row r holds image row (first image row of the tile) + r; the cell row `row` is relative to
-// the block, so template row u of that cell lies in tile row row + u.
+// Accumulate template rows [ub, ue) (chunk-relative) for the J cells of one strip.  Tile row r
+// holds image row (first image row of the tile) + r and the cell row `row` is relative to the
+// block, so template row u of that cell lies in tile row row + u.
 template <int J, bool BORDER>
-__device__ __forceinline__ void strip_accumulate(const unsigned* __restrict__ tile, const unsigned* __restrict__ vtile,
-                                                 int tp, const uint2* __restrict__ tmpl, int G, int ub, int ue,
-                                                 int row, int strip, unsigned (&cc)[J], unsigned (&si)[J], unsigned (&sp)[J]) {
+__device__ __forceinline__ void strip_accumulate(const lds_u32* tile, const lds_u32* vtile, int tp,
+                                                 const lds_u64* tmpl, int G, int ub, int ue, int row, int strip,
+                                                 unsigned (&cc)[J], unsigned (&si)[J], unsigned (&sp)[J]) {
     constexpr int JD = J / 4;
     for (int u = ub; u < ue; ++u) {
         const int tofs = (row + u) * tp + strip * JD;
-        const unsigned* tr = tile + tofs;
-        const unsigned* vr = vtile + tofs;
-        const uint2* pr = tmpl + u * G;
+        const lds_u32* tr = tile + tofs;
+        const lds_u32* vr = vtile + tofs;
+        const lds_u64* pr = tmpl + u * G;
         unsigned d0 = tr[0], d1 = (JD == 2) ? tr[1] : 0u;
         unsigned v0 = 0, v1 = 0;
         if (BORDER) { v0 = vr[0]; v1 = (JD == 2) ? vr[1] : 0u; }
 #pragma unroll 2
         for (int g = 0; g < G; ++g) {
             const unsigned dn = tr[g + JD];
-            const uint2 pm = pr[g];
-            const unsigned P0 = pm.x, M = pm.y;
+            const unsigned long long pm = pr[g];
+            const unsigned P0 = (unsigned)pm, M = (unsigned)(pm >> 32);
             unsigned sel[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) sel[k] = bfi32(M, 0x03020100u + 0x01010101u * (unsigned)k, 0x0C0C0C0Cu);
@@ -94,49 +97,54 @@ __device__ __forceinline__ float finalize_cell(const Geo& g, int x, int y, unsig
     return score_f32(CC, SI, SPc);
 }
 
-// One block of cells [xb, xb+BW) x [yb, yb+bh) (xb may be < 0: columns left of 0 and right of aw
-// are padding).  J cells per strip.
+template <bool BIG>
+__device__ __forceinline__ unsigned long long acc_read(const lds_u8* acc, int i) {
+    if (BIG) return reinterpret_cast<const lds_u64*>(acc)[i];
+    return reinterpret_cast<const lds_u32*>(acc)[i];
+}
+
+// Score of block cell (x,y) from the block's accumulators (x,y must be cells of that block).
 template <int J, bool BORDER, bool BIG>
-__device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm,
-                                           unsigned char* lds, int xb, int yb, int strips, int bh, int UR, int S,
-                                           int G, bool first_block, unsigned long long& sp_part, Best& best) {
-    const int tid = threadIdx.x;
-    unsigned* acc = reinterpret_cast<unsigned*>(lds);
-    uint2* tmpl = reinterpret_cast<uint2*>(lds + FAST_ACC_BYTES);
-    unsigned* tile = reinterpret_cast<unsigned*>(lds + FAST_ACC_BYTES + FAST_TMPL_BYTES);
+__device__ __forceinline__ float cell_from_acc(const Geo& g, const lds_u8* acc, int xb, int yb, int strips,
+                                               int x, int y, unsigned long long spfull) {
+    constexpr int AW = BORDER ? 3 : 2;
+    const int c = ((y - yb) * strips) * J + (x - xb);      // (row*strips + strip)*J + k
+    const unsigned long long CC = acc_read<BIG>(acc, c * AW + 0);
+    const unsigned long long SI = acc_read<BIG>(acc, c * AW + 1);
+    const unsigned long long SP = BORDER ? acc_read<BIG>(acc, c * AW + 2) : 0ull;
+    return finalize_cell(g, x, y, CC, SI, SP, spfull);
+}
+
+// One block of cells [xb, xb + strips*J) x [yb, yb+bh) (xb may be < 0: columns left of 0 and right
+// of aw are padding).  Adds the block's scores to the running argmax.
+template <int J, bool BORDER, bool BIG>
+__device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds,
+                                           int xb, int yb, int strips, int bh, int UR, int S, int G,
+                                           bool first_block, unsigned long long& spfull, Best& best) {
+    const int lane = threadIdx.x;
     constexpr int JD = J / 4;
+    constexpr int AW = BORDER ? 3 : 2;
+    lds_u8* acc = lds;
+    lds_u64* tmpl = reinterpret_cast<lds_u64*>(lds + FAST_ACC_BYTES);
+    lds_u32* tile = reinterpret_cast<lds_u32*>(lds + FAST_ACC_BYTES + FAST_TMPL_BYTES);
     const int tp = (strips * JD + G) | 1;                  // odd dword pitch: rows spread over the banks
     const int trows_max = (FAST_TILE_BYTES / 4 / (BORDER ? 2 : 1)) / tp;
-    unsigned* vtile = tile + trows_max * tp;
+    lds_u32* vtile = tile + trows_max * tp;
     const int units = strips * bh;
     const int ntask = units * S;
+    const int ncell = units * J;
     const int ix0 = g.x0 + xb;                             // image column of tile column 0 (multiple of 4)
     const bool aligned = ((reinterpret_cast<unsigned long long>(g.im) | (unsigned long long)g.ipitch) & 3ull) == 0;
+    unsigned long long sp_part = 0;
 
-    // this lane's task
-    const bool active = tid < ntask;
-    const int unit = active ? tid / S : 0;
-    const int slice = active ? tid - unit * S : 0;
-    const int row = unit / strips, strip = unit - row * strips;
-
-    unsigned cc[J], si[J], sp[J];
-    unsigned long long tcc[BIG ? J : 1], tsi[BIG ? J : 1], tsp[BIG ? J : 1];
-#pragma unroll
-    for (int k = 0; k < J; k++) { cc[k] = 0; si[k] = 0; sp[k] = 0; }
-    if (BIG) {
-#pragma unroll
-        for (int k = 0; k < J; k++) { tcc[k] = 0; tsi[k] = 0; tsp[k] = 0; }
-    }
     __syncthreads();                                       // the previous block's finalize has read acc
-    if (S > 1) {
-        for (int i = tid; i < units * J * 3; i += SLAM_WG) acc[i] = 0;
-    }
+    for (int i = lane; i < ncell * AW * (BIG ? 2 : 1); i += SLAM_WG) reinterpret_cast<lds_u32*>(acc)[i] = 0;
 
     for (int u0 = 0; u0 < g.ph; u0 += UR) {
         const int ur = min(UR, g.ph - u0);
         __syncthreads();                                   // previous chunk's readers are done
         // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
-        for (int i = tid; i < ur * G; i += SLAM_WG) {
+        for (int i = lane; i < ur * G; i += SLAM_WG) {
             const int u = i / G, gg = i - u * G;
             unsigned P0 = 0, M = 0;
 #pragma unroll
@@ -151,12 +159,12 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
                     if (first_block) sp_part += p * p;
                 }
             }
-            tmpl[i] = make_uint2(P0, M);
+            tmpl[i] = ((unsigned long long)M << 32) | P0;
         }
         // ---- stage the image tile (and its validity) --------------------------------------------
         const int trows = bh + ur - 1;
         const int iy0 = g.y0 + yb + u0;
-        for (int i = tid; i < trows * tp; i += SLAM_WG) {
+        for (int i = lane; i < trows * tp; i += SLAM_WG) {
             const int r = i / tp, c = i - r * tp;
             const int iy = iy0 + r, ix = ix0 + 4 * c;
             unsigned px = 0, vv = 0;
@@ -176,89 +184,85 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
             if (BORDER) vtile[i] = vv;
         }
         __syncthreads();
-        // ---- accumulate ---------------------------------------------------------------------------
-        if (active) {
+        // ---- accumulate: the lanes walk the (strip, row-slice) tasks -----------------------------
+        for (int task = lane; task < ntask; task += SLAM_WG) {
+            const int unit = task / S, slice = task - unit * S;
+            const int row = unit / strips, strip = unit - row * strips;
             const int ub = (slice * ur) / S, ue = ((slice + 1) * ur) / S;
-            strip_accumulate<J, BORDER>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
-        }
-        if (BIG) {
+            unsigned cc[J], si[J], sp[J];
 #pragma unroll
-            for (int k = 0; k < J; k++) { tcc[k] += cc[k]; tsi[k] += si[k]; tsp[k] += sp[k]; cc[k] = 0; si[k] = 0; sp[k] = 0; }
-        }
-    }
-
-    // |patch0|^2 over the whole template, once per job
-    if (first_block) {
-        const unsigned long long s = wave_sum_u64(sp_part);
-        if ((tid & 63) == 0) sm.red64[tid >> 6] = s;
-        __syncthreads();
-        if (tid == 0) sm.spfull = sm.red64[0] + sm.red64[1] + sm.red64[2] + sm.red64[3];
-    }
-    if (S > 1) {
-        if (active) {
+            for (int k = 0; k < J; k++) { cc[k] = 0; si[k] = 0; sp[k] = 0; }
+            strip_accumulate<J, BORDER>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
 #pragma unroll
             for (int k = 0; k < J; k++) {
-                atomicAdd(&acc[(unit * J + k) * 3 + 0], cc[k]);
-                atomicAdd(&acc[(unit * J + k) * 3 + 1], si[k]);
-                if (BORDER) atomicAdd(&acc[(unit * J + k) * 3 + 2], sp[k]);
+                const int a = (unit * J + k) * AW;
+                if (BIG) {
+                    lds_u64* a64 = reinterpret_cast<lds_u64*>(acc);
+                    __hip_atomic_fetch_add(a64 + a, (unsigned long long)cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(a64 + a + 1, (unsigned long long)si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (BORDER) __hip_atomic_fetch_add(a64 + a + 2, (unsigned long long)sp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    lds_u32* a32 = reinterpret_cast<lds_u32*>(acc);
+                    __hip_atomic_fetch_add(a32 + a, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(a32 + a + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (BORDER) __hip_atomic_fetch_add(a32 + a + 2, sp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
     }
+    if (first_block) spfull = wave_sum_u64(sp_part);       // |patch0|^2 over the whole template
     __syncthreads();
-    const unsigned long long spfull = sm.spfull;
 
     // ---- finalize: scores of the block's cells, running argmax -----------------------------------
-    if (S > 1) {
-        for (int c = tid; c < units * J; c += SLAM_WG) {
-            const int un = c / J, k = c - un * J;
-            const int r = un / strips, st = un - r * strips;
-            const int x = xb + st * J + k, y = yb + r;
-            if (x < 0 || x >= g.aw) continue;
-            const float sc = finalize_cell(g, x, y, acc[c * 3 + 0], acc[c * 3 + 1], acc[c * 3 + 2], spfull);
-            const int idx = y * g.aw + x;
-            if (scores) scores[idx] = sc;
-            best_update(best, sc, idx);
-        }
-    } else if (active) {
-#pragma unroll
-        for (int k = 0; k < J; k++) {
-            const int x = xb + strip * J + k, y = yb + row;
-            if (x < 0 || x >= g.aw) continue;
-            const unsigned long long CC = BIG ? tcc[k] : (unsigned long long)cc[k];
-            const unsigned long long SI = BIG ? tsi[k] : (unsigned long long)si[k];
-            const unsigned long long SP = BIG ? tsp[k] : (unsigned long long)sp[k];
-            const float sc = finalize_cell(g, x, y, CC, SI, SP, spfull);
-            const int idx = y * g.aw + x;
-            if (scores) scores[idx] = sc;
-            best_update(best, sc, idx);
-        }
+    for (int c = lane; c < ncell; c += SLAM_WG) {
+        const int un = c / J, k = c - un * J;
+        const int r = un / strips, st = un - r * strips;
+        const int x = xb + st * J + k, y = yb + r;
+        if (x < 0 || x >= g.aw) continue;
+        const float sc = cell_from_acc<J, BORDER, BIG>(g, acc, xb, yb, strips, x, y, spfull);
+        const int idx = y * g.aw + x;
+        if (scores) scores[idx] = sc;
+        best_update(best, sc, idx);
     }
 }
 
 // True when the tiled core can run this job; otherwise the caller uses direct evaluation.
 __device__ __forceinline__ bool fast_supported(const Geo& g) {
-    return (g.pw + 3) / 4 <= FAST_MAX_G && (long long)g.pw * g.ph <= 66051;   // 66051 * 255^2 < 2^32: u32 sums are exact
+    return (g.pw + 3) / 4 <= FAST_MAX_G;
+}
+
+// Row slices per strip: the S in [1, smax] that best fills the 64 lanes with strip x slice tasks.
+__device__ __forceinline__ int pick_slices(int units, int smax) {
+    int best_s = 1, best_u = 0;
+    for (int s = 1; s <= smax; s++) {
+        const int n = units * s;
+        const int u = n * 1000 / ((n + SLAM_WG - 1) / SLAM_WG * SLAM_WG);   // lane utilisation, per mille
+        if (u > best_u + 30) { best_u = u; best_s = s; }
+    }
+    return best_s;
 }
 
 template <int J>
-__device__ __forceinline__ void fast_blocks(const Geo& g, const Tmpl& t, float* scores, CoreShared& sm,
-                                            unsigned char* lds, Best& best) {
+__device__ __forceinline__ void fast_blocks(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds,
+                                            unsigned long long& spfull, Best& best, FastState& fs) {
     constexpr int JD = J / 4;
     const int G = (g.pw + 3) / 4;
+    const bool big = (long long)g.pw * g.ph > 66051;       // 66051 * 255^2 < 2^32: beyond it sums need 64 bits
     const int o = ((g.x0 % 4) + 4) & 3;                    // cells left of 0 that align the tile to image dwords
     const int BW = min((g.aw + o + J - 1) / J * J, 64);
     const int strips_max = BW / J;
-    // one plan per band of rows, sized for the widest block and for the two-tile (cropped) case
+    // one plan per band of rows, sized for the widest block and for the cropped (two-tile, 3-sum) case
     const int tp_max = (strips_max * JD + G) | 1;
     const int TR = max(1, (FAST_TILE_BYTES / 4 / 2) / tp_max);
-    unsigned long long sp_part = 0;
+    const int cap_cells = FAST_ACC_BYTES / (3 * (big ? 8 : 4));
     bool first = true;
+    int nblocks = 0;
     for (int yb = 0; yb < g.ah;) {
         int UR = min(min(g.ph, FAST_TMPL_BYTES / 8 / G), TR);
-        int BH = min(g.ah - yb, SLAM_WG / strips_max);
+        int BH = max(1, min(g.ah - yb, cap_cells / (strips_max * J)));
         if (BH + UR - 1 > TR) {
             // prefer whole-template chunks: shrink the block first, then the chunk
-            if (TR - UR + 1 >= 4 || UR == 1) BH = max(1, TR - UR + 1);
+            if (TR - UR + 1 >= 4 || UR == 1) BH = max(1, min(BH, TR - UR + 1));
             else { UR = max(1, TR / 2); BH = max(1, min(BH, TR - UR + 1)); }
         }
         for (int xb = -o; xb < g.aw; xb += BW) {
@@ -267,22 +271,43 @@ __device__ __forceinline__ void fast_blocks(const Geo& g, const Tmpl& t, float* 
             const int cx0 = max(xb, 0), cx1 = xb + bw;
             // does the block hold cells whose patch leaves the image?
             const bool border = cx0 < g.xl0 || cx1 > g.xl1 || yb < g.yl0 || yb + BH > g.yl1;
-            const int units = strips * BH;
-            int S = max(1, min(min(8, SLAM_WG / units), UR));
-            if (units * J * 12 > FAST_ACC_BYTES) S = 1;
-            if (border) fast_block<J, true, false>(g, t, scores, sm, lds, xb, yb, strips, BH, UR, S, G, first, sp_part, best);
-            else fast_block<J, false, false>(g, t, scores, sm, lds, xb, yb, strips, BH, UR, S, G, first, sp_part, best);
+            const int S = pick_slices(strips * BH, min(8, UR));
+            if (border) {
+                if (big) fast_block<J, true, true>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
+                else fast_block<J, true, false>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
+            } else {
+                if (big) fast_block<J, false, true>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
+                else fast_block<J, false, false>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
+            }
             first = false;
+            nblocks++;
+            fs.border = border; fs.big = big; fs.J = J; fs.xb = xb; fs.yb = yb; fs.strips = strips; fs.bh = BH;
         }
         yb += BH;
     }
+    fs.single_block = nblocks == 1;
 }
 
-// ops per useful cell and 4-pixel group for strips of J cells (4 selector ops + 3 per cell)
+// VALU operations per useful cell and 4-pixel group for strips of J cells (4 selector ops + 3 per cell)
 __device__ __forceinline__ int fast_cost(const Geo& g, int J) {
     const int o = ((g.x0 % 4) + 4) & 3;
     const int strips = (g.aw + o + J - 1) / J;
     return (4 + 3 * J) * strips;
+}
+
+// Score of a cell of the (single) block that is still held in the accumulators.
+__device__ __forceinline__ float fast_cell_score(const Geo& g, const lds_u8* lds, const FastState& fs,
+                                                 int x, int y, unsigned long long spfull) {
+    if (fs.J == 8) {
+        if (fs.border) return fs.big ? cell_from_acc<8, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
+                                     : cell_from_acc<8, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
+        return fs.big ? cell_from_acc<8, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
+                      : cell_from_acc<8, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
+    }
+    if (fs.border) return fs.big ? cell_from_acc<4, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
+                                 : cell_from_acc<4, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
+    return fs.big ? cell_from_acc<4, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
+                  : cell_from_acc<4, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
 }
 
 }  // namespace slamdev
