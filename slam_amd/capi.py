@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libslam_hip.so")
+LIB_PATH = os.environ.get("SLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libslam_hip.so")
 
 OK, EINVAL, EHIP, ENOMEM, ECAP = 0, -1, -2, -3, -4
 MAX_LEVELS = 8
@@ -60,6 +60,7 @@ SIGNATURES = {
     "slam_hip_destroy": (C.c_int, [_P]),
     "slam_hip_set_stream": (C.c_int, [_P, _P]),
     "slam_hip_synchronize": (C.c_int, [_P]),
+    "slam_hip_set_match_lds": (C.c_int, [_P, C.c_int]),
     "slam_hip_last_error_string": (C.c_char_p, [_P]),
     "slam_hip_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "slam_hip_free": (C.c_int, [_P, _P]),

@@ -45,6 +45,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     c->stream = c->own_stream;
     const char* fd = getenv("SLAM_HIP_FORCE_DIRECT");
     c->force_direct = (fd && fd[0] == '1') ? 1 : 0;
+    const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");
+    if (lk && atoi(lk) >= 4 && atoi(lk) <= 64) c->match_lds_bytes = atoi(lk) * 1024;
     *out = c;
     return SLAM_HIP_OK;
 }
@@ -63,6 +65,14 @@ extern "C" int slam_hip_destroy(slam_ctx* ctx) {
 extern "C" int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream) {
     if (!ctx) return SLAM_HIP_EINVAL;
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_set_match_lds(slam_ctx* ctx, int bytes) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (bytes < 4096 || bytes > 65536 || (bytes & 1023))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_match_lds: %d not a multiple of 1024 in [4096, 65536]", bytes);
+    ctx->match_lds_bytes = bytes;
     return SLAM_HIP_OK;
 }
 

@@ -17,7 +17,7 @@ static_assert(SLAM_WG == 64, "the search kernels assume one wavefront per workgr
 // Direct evaluation of every score cell the reference visits: one lane per cell, looping over the
 // template pixels.  Used for templates wider than the tiled core supports and as an in-GPU
 // cross-check of the tiled core (SLAM_HIP_FORCE_DIRECT=1).
-__device__ __forceinline__ void direct_cells(const Geo& g, const Tmpl& t, float* scores, unsigned long long& spfull, Best& b) {
+__device__ __forceinline__ void direct_cells(const Geo& g, const Tmpl& t, float* scores, unsigned long long& spfull, Norms& nm, Best& b) {
     const int lane = threadIdx.x;
     {   // |patch0|^2 over the whole template (matching.cpp:63,109; template norm of matchTemplate)
         unsigned long long sp = 0;
@@ -29,6 +29,7 @@ __device__ __forceinline__ void direct_cells(const Geo& g, const Tmpl& t, float*
             sp += p * p;
         }
         spfull = wave_sum_u64(sp);
+        nm = make_norms(spfull);
     }
     const int ncell = g.aw * g.ah;
     for (int c = lane; c < ncell; c += SLAM_WG) {
@@ -70,25 +71,29 @@ __device__ __forceinline__ float cell_score_coop(const Geo& g, const Tmpl& t, in
 struct CoreState {
     Best best;                  // wave-uniform after match_core
     unsigned long long spfull;
+    Norms nm;
     FastState fs;
     bool used_fast;
 };
 
 // SLAM::matchFeatureInArea for one job: score cells (tiled packed-u8 core or direct evaluation) and
 // the cv::minMaxLoc argmax.  The result is uniform over the wavefront.
-__device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, bool force_direct, CoreState& st) {
+__device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
+                                              bool force_direct, CoreState& st STAMP_ARG) {
     Best b = {-FLT_MAX, INT_MAX};
     st.spfull = 0;
+    st.nm = make_norms(0);
     st.fs.single_block = false;
     st.used_fast = !force_direct && fast_supported(g);
     if (st.used_fast) {
-        if (fast_cost(g, 8) < fast_cost(g, 4)) fast_blocks<8>(g, t, scores, lds, st.spfull, b, st.fs);
-        else fast_blocks<4>(g, t, scores, lds, st.spfull, b, st.fs);
+        if (fast_cost(g, 8) < fast_cost(g, 4)) fast_blocks<8>(g, t, scores, lds, lp, st.spfull, st.nm, b, st.fs STAMP_PASS);
+        else fast_blocks<4>(g, t, scores, lds, lp, st.spfull, st.nm, b, st.fs STAMP_PASS);
     } else {
-        direct_cells(g, t, scores, st.spfull, b);
+        direct_cells(g, t, scores, st.spfull, st.nm, b);
     }
     b = best_wave(b);
     st.best = b;
+    STAMP(20);
     CoreOut o;
     o.dx = 0.f; o.dy = 0.f;
     if (b.idx == INT_MAX) {      // nothing compared greater than -FLT_MAX: every cell is NaN
@@ -109,15 +114,22 @@ __device__ __forceinline__ void subpixel(const Geo& g, const Tmpl& t, const lds_
     const float s = st.best.v;
     float nb[4];
     bool ok[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
+    if (st.used_fast && st.fs.single_block) {
+        // lanes 0..3 each read one neighbour's sums from the block accumulators
+        const int n = threadIdx.x & 3;
         const int nx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0);
         const int ny = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
-        ok[n] = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
-        nb[n] = -1.f;
-        if (ok[n]) {
-            if (st.used_fast && st.fs.single_block) nb[n] = fast_cell_score(g, lds, st.fs, nx, ny, st.spfull);
-            else nb[n] = cell_score_coop(g, t, nx, ny, st.spfull);
+        const bool in = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
+        const float v = in ? fast_cell_score(g, lds, st.fs, nx, ny, st.nm) : -1.f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { nb[k] = __shfl(v, k, 64); ok[k] = __shfl((int)in, k, 64) != 0; }
+    } else {
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const int nx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0);
+            const int ny = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
+            ok[n] = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
+            nb[n] = ok[n] ? cell_score_coop(g, t, nx, ny, st.spfull) : -1.f;
         }
     }
     if (ok[0] && ok[1] && nb[0] != -1.f && nb[1] != -1.f && nb[0] == nb[0] && nb[1] == nb[1]) {
@@ -144,9 +156,10 @@ __global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, con
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes, float* scores,
                                                         unsigned long long scores_len,
-                                                        slam_match_result* __restrict__ out, int force_direct) {
+                                                        slam_match_result* __restrict__ out, int force_direct, int lds_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
+    const LdsPlan plan = make_lds_plan(lds_total);
     const int j = blockIdx.x;
     if (j >= njobs) return;
     const slam_match_job job = jobs[j];
@@ -188,7 +201,8 @@ __global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, con
     t.srcw = job.pw; t.srch = job.ph; t.tw = job.pw; t.th = job.ph; t.resized = false;
     t.scale_x = 1.0; t.scale_y = 1.0;
     CoreState st;
-    CoreOut o = match_core(g, t, sc, lds, force_direct != 0, st);
+    STAMP_DECL;
+    CoreOut o = match_core(g, t, sc, lds, plan, force_direct != 0, st STAMP_PASS);
     subpixel(g, t, lds, st, o);
     if (threadIdx.x == 0) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
 }
@@ -196,9 +210,10 @@ __global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, con
 __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
-                                                        slam_track_result* __restrict__ out, int force_direct) {
+                                                        slam_track_result* __restrict__ out, int force_direct, int lds_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
+    const LdsPlan plan = make_lds_plan(lds_total);
     const int j = blockIdx.x;
     if (j >= njobs) return;
     const slam_track_job job = jobs[j];
@@ -221,6 +236,8 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
     t.srcw = job.projw; t.srch = job.projh;
     t.scale_x = 1.0; t.scale_y = 1.0;
 
+    STAMP_DECL;
+    STAMP(1);
     float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
     float response = 0.f, sdx = 0.f, sdy = 0.f;
     int levels_run = 0;
@@ -259,19 +276,22 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
         int mx = 0, my = 0;
         sdx = 0.f; sdy = 0.f;
         levels_run++;
+        STAMP(2);
         if (g.reject) { response = -1.f; }       // matching.cpp:26-30
         else {
             CoreState st;
-            CoreOut o = match_core(g, t, nullptr, lds, force_direct != 0, st);
+            CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, st STAMP_PASS);
             mx = o.x; my = o.y; response = o.response;
             // feature.cpp:151-152; the sub-pixel fit is only reported for the last level run
             const bool last = (i == 0) || ((double)response < __dmul_rn(0.67, (double)job.threshold));
             if (last) { subpixel(g, t, lds, st, o); sdx = o.dx; sdy = o.dy; }
+            STAMP(21);
         }
         tx = __fmul_rn((float)mx, sub);          // feature.cpp:150
         ty = __fmul_rn((float)my, sub);
         if ((double)response < __dmul_rn(0.67, (double)job.threshold)) break;   // feature.cpp:151-152
     }
+    STAMP(30);
     if (tid == 0) {
         slam_track_result r;
         if (empty_level) { r.x = -1; r.y = -1; r.response = -1.f; r.dx = 0.f; r.dy = 0.f; r.levels_run = levels_run; }
@@ -297,6 +317,12 @@ int check_pyr(slam_ctx* ctx, const slam_pyr* pyr, const char* who) {
 
 }  // namespace
 
+#ifdef SLAM_STAMPS
+extern "C" int slam_hip_debug_set_stamps(void* d_ptr) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_slam_stamps), &d_ptr, sizeof(void*)) == hipSuccess ? 0 : -2;
+}
+#endif
+
 extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_match_job* d_jobs,
                                       int njobs, const uint8_t* d_blob, size_t blob_bytes,
                                       float* d_scores, size_t scores_len, slam_match_result* d_out) {
@@ -307,9 +333,9 @@ extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), FAST_LDS_BYTES, ctx->stream,
+    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
-                       (unsigned long long)scores_len, d_out, ctx->force_direct);
+                       (unsigned long long)scores_len, d_out, ctx->force_direct, ctx->match_lds_bytes);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }
@@ -407,9 +433,9 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), FAST_LDS_BYTES,
+    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                       ctx->force_direct);
+                       ctx->force_direct, ctx->match_lds_bytes);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }

@@ -9,6 +9,30 @@
 #define SLAM_WG 64           // one wavefront per job: no cross-wave synchronisation, many jobs per CU
 #define SLAM_MAX_TMPL 512    // max template width/height of a track job (the reference caps projections at 500)
 
+// Diagnostic build only (-DSLAM_STAMPS, `make stamps`): lane 0 of every job records s_memtime at
+// phase boundaries into a buffer of its own; the product build compiles STAMP() to nothing.
+#ifdef SLAM_STAMPS
+#define SLAM_STAMP_SLOTS 64
+__device__ unsigned long long* g_slam_stamps = nullptr;
+__device__ __forceinline__ void slam_stamp(int& slot, int id) {
+    if (g_slam_stamps && threadIdx.x == 0 && slot < SLAM_STAMP_SLOTS) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        g_slam_stamps[(size_t)blockIdx.x * SLAM_STAMP_SLOTS + slot] = (t << 8) | (unsigned)id;
+    }
+    slot++;
+}
+#define STAMP(id) slam_stamp(stamp_slot, (id))
+#define STAMP_DECL int stamp_slot = 0
+#define STAMP_ARG , int& stamp_slot
+#define STAMP_PASS , stamp_slot
+#else
+#define STAMP(id) ((void)0)
+#define STAMP_DECL ((void)0)
+#define STAMP_ARG
+#define STAMP_PASS
+#endif
+
 namespace slamdev {
 
 // ---- score formulas -------------------------------------------------------------------------
@@ -34,6 +58,37 @@ __device__ __forceinline__ float score_mt(unsigned long long CC, unsigned long l
     return (float)num;
 }
 
+// The same two formulas with the template-side factor computed once per job:
+//   p2f = (float)sqrt((double)SP) for the f32 formula, tn = sqrt((double)SP) for matchTemplate.
+struct Norms { float p2f; double tn; };
+
+__device__ __forceinline__ Norms make_norms(unsigned long long SP) {
+    Norms n;
+    n.tn = __dsqrt_rn((double)SP);
+    n.p2f = (float)n.tn;
+    return n;
+}
+
+__device__ __forceinline__ float score_f32_n(unsigned long long CC, unsigned long long SI, float p2f) {
+    const float cc = (float)(double)CC;
+    const float i2 = (float)__dsqrt_rn((double)SI);
+    return __fdiv_rn(cc, __fmul_rn(i2, p2f));
+}
+
+__device__ __forceinline__ float score_mt_n(unsigned long long CC, unsigned long long SI, double tn) {
+    double num = (double)CC;
+    const double t = __dmul_rn(__dsqrt_rn((double)SI), tn);
+    if (fabs(num) < t) num = __ddiv_rn(num, t);
+    else if (fabs(num) < __dmul_rn(t, 1.125)) num = num > 0 ? 1.0 : -1.0;
+    else num = 0.0;
+    return (float)num;
+}
+
+// exact unsigned division by a small runtime constant d via its reciprocal rcp = ceil(2^32/d);
+// valid while n*d < 2^32
+__device__ __forceinline__ unsigned rcp_u32(unsigned d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ unsigned div_rcp(unsigned n, unsigned d, unsigned rcp) { return d == 1 ? n : __umulhi(n, rcp); }
+
 // ---- geometry -------------------------------------------------------------------------------
 struct Geo {
     const uint8_t* im;        // level image of the job's frame
@@ -46,6 +101,7 @@ struct Geo {
     int x0, y0;               // image position of patch pixel (0,0) for cell (0,0) (matching.cpp:38-39)
     int xl0, xl1, yl0, yl1;   // cells whose whole patch is inside the image (matching.cpp:44-49)
     int stride;
+    unsigned sinv;            // ceil(2^32 / stride): n % stride without a division for n*stride < 2^32
     int yf;                   // first multiple of stride >= yl0
     bool masked;              // patchMask given
     bool exact;               // useExactAreaMask
@@ -75,7 +131,14 @@ __device__ __forceinline__ Geo make_geo(const uint8_t* im, int w, int h, long lo
     g.xl0 = x0ua - g.x0; g.xl1 = x1ua - g.x0 - pw + 1;
     g.yl0 = y0ua - g.y0; g.yl1 = y1ua - g.y0 - ph + 1;
     g.yf = (g.yl0 + stride - 1) / stride * stride;
+    g.sinv = (unsigned)((0x100000000ull + (unsigned)stride - 1) / (unsigned)stride);
     return g;
+}
+
+// n % g.stride for 0 <= n < 2^20 (stride <= 1024 keeps n*stride < 2^32, where the reciprocal is exact)
+__device__ __forceinline__ int mod_stride(const Geo& g, int n) {
+    if (g.stride > 4096) return n % g.stride;
+    return n - (int)__umulhi((unsigned)n, g.sinv) * g.stride;
 }
 
 enum CellKind { CELL_NONE = 0, CELL_F32_FULL = 1, CELL_MT = 2, CELL_F32_CROP = 3 };
@@ -92,19 +155,19 @@ __device__ __forceinline__ int classify_cell(const Geo& g, int x, int y) {
     const bool am = !g.amask || g.amask[(long long)y * g.ampitch + x] != 0;
     if (interior) {
         if (g.masked) {
-            if (g.stride != 1 && (((x - g.xl0) % g.stride) != 0 || ((y - g.yl0) % g.stride) != 0)) return CELL_NONE;
+            if (g.stride != 1 && (mod_stride(g, x - g.xl0) != 0 || mod_stride(g, y - g.yl0) != 0)) return CELL_NONE;
             return am ? CELL_F32_FULL : CELL_NONE;
         }
         if (g.exact && !am) return CELL_NONE;
         return CELL_MT;
     }
     if (g.stride != 1) {
-        if ((x % g.stride) != 0) return CELL_NONE;
+        if (mod_stride(g, x) != 0) return CELL_NONE;
         bool on;
         if (inx && g.yf < g.yl1)   // this column's walk hits the interior block at yf and jumps to yl1
-            on = (y < g.yl0) ? ((y % g.stride) == 0) : ((y >= g.yl1) && (((y - g.yl1) % g.stride) == 0));
+            on = (y < g.yl0) ? (mod_stride(g, y) == 0) : ((y >= g.yl1) && (mod_stride(g, y - g.yl1) == 0));
         else
-            on = (y % g.stride) == 0;
+            on = mod_stride(g, y) == 0;
         if (!on) return CELL_NONE;
     }
     if (!am) return CELL_NONE;

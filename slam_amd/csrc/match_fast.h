@@ -1,6 +1,6 @@
 // LDS-tiled packed-u8 search core: one wavefront (64 lanes) per job.
 //
-// Data layout in LDS (dynamic, FAST_LDS_BYTES):
+// Data layout in LDS (dynamic; the launch gives lds_total bytes, split by LdsPlan):
 //   acc   : per-cell sums {CC, SI[, SPcrop]} of the current block (u32, or u64 for templates of
 //           more than 66051 pixels), accumulated with LDS atomics
 //   tmpl  : the current chunk of template rows, one 8-byte entry per 4-pixel group:
@@ -20,10 +20,9 @@
 
 #include "match_common.h"
 
-#define FAST_ACC_BYTES (8 * 1024)
-#define FAST_TMPL_BYTES (3 * 1024)
-#define FAST_TILE_BYTES (5 * 1024)
-#define FAST_LDS_BYTES (FAST_ACC_BYTES + FAST_TMPL_BYTES + FAST_TILE_BYTES)
+#define FAST_LDS_DEFAULT (16 * 1024)
+#define FAST_LDS_MIN (4 * 1024)
+#define FAST_LDS_MAX (64 * 1024)
 #define FAST_MAX_G 96         // template width up to 384 pixels; wider ones use direct evaluation
 
 namespace slamdev {
@@ -33,6 +32,19 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
 struct CoreOut { int x, y; float response, dx, dy; };
+
+// Split of the job's LDS: half for the accumulators, 3/16 for the template chunk, 5/16 for the tile.
+struct LdsPlan {
+    int acc_bytes, tmpl_bytes, tile_bytes;
+};
+
+__device__ __forceinline__ LdsPlan make_lds_plan(int lds_total) {
+    LdsPlan p;
+    p.acc_bytes = (lds_total / 2) & ~15;
+    p.tmpl_bytes = (lds_total * 3 / 16) & ~15;
+    p.tile_bytes = (lds_total - p.acc_bytes - p.tmpl_bytes) & ~15;
+    return p;
+}
 
 // What the tiled core leaves behind for the sub-pixel fit when the whole score map was one block.
 struct FastState {
@@ -89,11 +101,11 @@ __device__ __forceinline__ void strip_accumulate(const lds_u32* tile, const lds_
 }
 
 __device__ __forceinline__ float finalize_cell(const Geo& g, int x, int y, unsigned long long CC,
-                                               unsigned long long SI, unsigned long long SPc, unsigned long long spfull) {
+                                               unsigned long long SI, unsigned long long SPc, const Norms& nm) {
     const int kind = classify_cell(g, x, y);
     if (kind == CELL_NONE) return -1.f;                    // matching.cpp:53
-    if (kind == CELL_MT) return score_mt(CC, SI, spfull);
-    if (kind == CELL_F32_FULL) return score_f32(CC, SI, spfull);
+    if (kind == CELL_MT) return score_mt_n(CC, SI, nm.tn);
+    if (kind == CELL_F32_FULL) return score_f32_n(CC, SI, nm.p2f);
     return score_f32(CC, SI, SPc);
 }
 
@@ -106,35 +118,60 @@ __device__ __forceinline__ unsigned long long acc_read(const lds_u8* acc, int i)
 // Score of block cell (x,y) from the block's accumulators (x,y must be cells of that block).
 template <int J, bool BORDER, bool BIG>
 __device__ __forceinline__ float cell_from_acc(const Geo& g, const lds_u8* acc, int xb, int yb, int strips,
-                                               int x, int y, unsigned long long spfull) {
+                                               int x, int y, const Norms& nm) {
     constexpr int AW = BORDER ? 3 : 2;
     const int c = ((y - yb) * strips) * J + (x - xb);      // (row*strips + strip)*J + k
     const unsigned long long CC = acc_read<BIG>(acc, c * AW + 0);
     const unsigned long long SI = acc_read<BIG>(acc, c * AW + 1);
     const unsigned long long SP = BORDER ? acc_read<BIG>(acc, c * AW + 2) : 0ull;
-    return finalize_cell(g, x, y, CC, SI, SP, spfull);
+    return finalize_cell(g, x, y, CC, SI, SP, nm);
+}
+
+// Lane -> (row, column) walk over a rows x width rectangle without per-element divisions:
+// when width <= 64 a lane keeps its column and steps rows by 64/width, else rows are done one at a
+// time with the lanes striding over the columns.
+struct Walk2D {
+    int r0, c0, rstep, cstep;
+};
+
+__device__ __forceinline__ Walk2D make_walk(int width, int rows) {
+    Walk2D w;
+    const int lane = threadIdx.x;
+    if (width <= SLAM_WG) {
+        const int per = SLAM_WG / width;                   // rows handled per pass
+        const int lr = lane / width;
+        w.c0 = lane - lr * width;
+        w.r0 = lr < per ? lr : rows;                       // surplus lanes do nothing
+        w.rstep = per;
+        w.cstep = width;
+    } else {
+        w.r0 = 0; w.c0 = lane; w.rstep = 1; w.cstep = SLAM_WG;
+    }
+    return w;
 }
 
 // One block of cells [xb, xb + strips*J) x [yb, yb+bh) (xb may be < 0: columns left of 0 and right
 // of aw are padding).  Adds the block's scores to the running argmax.
 template <int J, bool BORDER, bool BIG>
-__device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds,
+__device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
                                            int xb, int yb, int strips, int bh, int UR, int S, int G,
-                                           bool first_block, unsigned long long& spfull, Best& best) {
+                                           bool first_block, unsigned long long& spfull, Norms& nm, Best& best STAMP_ARG) {
     const int lane = threadIdx.x;
     constexpr int JD = J / 4;
     constexpr int AW = BORDER ? 3 : 2;
     lds_u8* acc = lds;
-    lds_u64* tmpl = reinterpret_cast<lds_u64*>(lds + FAST_ACC_BYTES);
-    lds_u32* tile = reinterpret_cast<lds_u32*>(lds + FAST_ACC_BYTES + FAST_TMPL_BYTES);
+    lds_u64* tmpl = reinterpret_cast<lds_u64*>(lds + lp.acc_bytes);
+    lds_u32* tile = reinterpret_cast<lds_u32*>(lds + lp.acc_bytes + lp.tmpl_bytes);
     const int tp = (strips * JD + G) | 1;                  // odd dword pitch: rows spread over the banks
-    const int trows_max = (FAST_TILE_BYTES / 4 / (BORDER ? 2 : 1)) / tp;
+    const int trows_max = (lp.tile_bytes / 4 / (BORDER ? 2 : 1)) / tp;
     lds_u32* vtile = tile + trows_max * tp;
+    const int width = strips * J;                          // cells per block row, <= 64
     const int units = strips * bh;
     const int ntask = units * S;
     const int ncell = units * J;
     const int ix0 = g.x0 + xb;                             // image column of tile column 0 (multiple of 4)
     const bool aligned = ((reinterpret_cast<unsigned long long>(g.im) | (unsigned long long)g.ipitch) & 3ull) == 0;
+    const unsigned rcpS = rcp_u32((unsigned)S), rcpStrips = rcp_u32((unsigned)strips);
     unsigned long long sp_part = 0;
 
     __syncthreads();                                       // the previous block's finalize has read acc
@@ -143,51 +180,80 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
     for (int u0 = 0; u0 < g.ph; u0 += UR) {
         const int ur = min(UR, g.ph - u0);
         __syncthreads();                                   // previous chunk's readers are done
+        STAMP(10);
         // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
-        for (int i = lane; i < ur * G; i += SLAM_WG) {
-            const int u = i / G, gg = i - u * G;
-            unsigned P0 = 0, M = 0;
+        {
+            const Walk2D w = make_walk(G, ur);
+            for (int u = w.r0; u < ur; u += w.rstep)
+                for (int gg = w.c0; gg < G; gg += w.cstep) {
+                    unsigned P0 = 0, M = 0;
+                    if (!t.resized) {
+                        const long long o = (long long)(u0 + u) * t.srcw + gg * 4;
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int v = gg * 4 + b;
-                if (v < g.pw) {
-                    unsigned p, m;
-                    tmpl_fetch(t, u0 + u, v, p, m);
-                    p *= m;
-                    P0 |= p << (8 * b);
-                    M |= (m ? 0xFFu : 0u) << (8 * b);
-                    if (first_block) sp_part += p * p;
+                        for (int b = 0; b < 4; b++)
+                            if (gg * 4 + b < g.pw) {
+                                unsigned p = t.patch[o + b];
+                                const unsigned m = t.mask ? (unsigned)(t.mask[o + b] != 0) : 1u;
+                                p *= m;
+                                P0 |= p << (8 * b);
+                                M |= (m ? 0xFFu : 0u) << (8 * b);
+                                if (first_block) sp_part += p * p;
+                            }
+                    } else {
+                        int sy, b0, b1;
+                        resize_tap(u0 + u, t.scale_y, t.srch, false, sy, b0, b1);
+#pragma unroll
+                        for (int b = 0; b < 4; b++)
+                            if (gg * 4 + b < g.pw) {
+                                int sx, a0, a1;
+                                resize_tap(gg * 4 + b, t.scale_x, t.srcw, true, sx, a0, a1);
+                                unsigned p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, false);
+                                const unsigned m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, true) != 0) : 1u;
+                                p *= m;
+                                P0 |= p << (8 * b);
+                                M |= (m ? 0xFFu : 0u) << (8 * b);
+                                if (first_block) sp_part += p * p;
+                            }
+                    }
+                    tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
                 }
-            }
-            tmpl[i] = ((unsigned long long)M << 32) | P0;
         }
+        STAMP(11);
         // ---- stage the image tile (and its validity) --------------------------------------------
-        const int trows = bh + ur - 1;
-        const int iy0 = g.y0 + yb + u0;
-        for (int i = lane; i < trows * tp; i += SLAM_WG) {
-            const int r = i / tp, c = i - r * tp;
-            const int iy = iy0 + r, ix = ix0 + 4 * c;
-            unsigned px = 0, vv = 0;
-            if (iy >= 0 && iy < g.h && ix + 3 >= 0 && ix < g.w) {
-                const uint8_t* src = g.im + (long long)iy * g.ipitch + ix;
-                if (ix >= 0 && ix + 3 < g.w) {
-                    vv = 0xFFFFFFFFu;
-                    if (aligned) px = *reinterpret_cast<const unsigned*>(src);
-                    else px = (unsigned)src[0] | ((unsigned)src[1] << 8) | ((unsigned)src[2] << 16) | ((unsigned)src[3] << 24);
-                } else {
+        {
+            const int trows = bh + ur - 1;
+            const int iy0 = g.y0 + yb + u0;
+            const Walk2D w = make_walk(tp, trows);
+            for (int r = w.r0; r < trows; r += w.rstep) {
+                const int iy = iy0 + r;
+                const bool rowin = iy >= 0 && iy < g.h;
+                const uint8_t* srow = g.im + (long long)iy * g.ipitch;
+                for (int c = w.c0; c < tp; c += w.cstep) {
+                    const int ix = ix0 + 4 * c;
+                    unsigned px = 0, vv = 0;
+                    if (rowin && ix + 3 >= 0 && ix < g.w) {
+                        const uint8_t* src = srow + ix;
+                        if (ix >= 0 && ix + 3 < g.w) {
+                            vv = 0xFFFFFFFFu;
+                            if (aligned) px = *reinterpret_cast<const unsigned*>(src);
+                            else px = (unsigned)src[0] | ((unsigned)src[1] << 8) | ((unsigned)src[2] << 16) | ((unsigned)src[3] << 24);
+                        } else {
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (ix + b >= 0 && ix + b < g.w) { px |= (unsigned)src[b] << (8 * b); vv |= 0xFFu << (8 * b); }
+                            for (int b = 0; b < 4; b++)
+                                if (ix + b >= 0 && ix + b < g.w) { px |= (unsigned)src[b] << (8 * b); vv |= 0xFFu << (8 * b); }
+                        }
+                    }
+                    tile[r * tp + c] = px;
+                    if (BORDER) vtile[r * tp + c] = vv;
                 }
             }
-            tile[i] = px;
-            if (BORDER) vtile[i] = vv;
         }
         __syncthreads();
+        STAMP(12);
         // ---- accumulate: the lanes walk the (strip, row-slice) tasks -----------------------------
         for (int task = lane; task < ntask; task += SLAM_WG) {
-            const int unit = task / S, slice = task - unit * S;
-            const int row = unit / strips, strip = unit - row * strips;
+            const int unit = (int)div_rcp((unsigned)task, (unsigned)S, rcpS), slice = task - unit * S;
+            const int row = (int)div_rcp((unsigned)unit, (unsigned)strips, rcpStrips), strip = unit - row * strips;
             const int ub = (slice * ur) / S, ue = ((slice + 1) * ur) / S;
             unsigned cc[J], si[J], sp[J];
 #pragma unroll
@@ -210,20 +276,27 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
             }
         }
     }
-    if (first_block) spfull = wave_sum_u64(sp_part);       // |patch0|^2 over the whole template
+    STAMP(13);
+    if (first_block) {                                     // |patch0|^2 over the whole template
+        spfull = wave_sum_u64(sp_part);
+        nm = make_norms(spfull);
+    }
     __syncthreads();
 
     // ---- finalize: scores of the block's cells, running argmax -----------------------------------
-    for (int c = lane; c < ncell; c += SLAM_WG) {
-        const int un = c / J, k = c - un * J;
-        const int r = un / strips, st = un - r * strips;
-        const int x = xb + st * J + k, y = yb + r;
-        if (x < 0 || x >= g.aw) continue;
-        const float sc = cell_from_acc<J, BORDER, BIG>(g, acc, xb, yb, strips, x, y, spfull);
-        const int idx = y * g.aw + x;
-        if (scores) scores[idx] = sc;
-        best_update(best, sc, idx);
+    {
+        const Walk2D w = make_walk(width, bh);
+        const int x = xb + w.c0;
+        if (x >= 0 && x < g.aw)
+            for (int r = w.r0; r < bh; r += w.rstep) {
+                const int y = yb + r;
+                const float sc = cell_from_acc<J, BORDER, BIG>(g, acc, xb, yb, strips, x, y, nm);
+                const int idx = y * g.aw + x;
+                if (scores) scores[idx] = sc;
+                best_update(best, sc, idx);
+            }
     }
+    STAMP(14);
 }
 
 // True when the tiled core can run this job; otherwise the caller uses direct evaluation.
@@ -243,22 +316,24 @@ __device__ __forceinline__ int pick_slices(int units, int smax) {
 }
 
 template <int J>
-__device__ __forceinline__ void fast_blocks(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds,
-                                            unsigned long long& spfull, Best& best, FastState& fs) {
+__device__ __forceinline__ void fast_blocks(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
+                                            unsigned long long& spfull, Norms& nm, Best& best, FastState& fs STAMP_ARG) {
     constexpr int JD = J / 4;
     const int G = (g.pw + 3) / 4;
     const bool big = (long long)g.pw * g.ph > 66051;       // 66051 * 255^2 < 2^32: beyond it sums need 64 bits
     const int o = ((g.x0 % 4) + 4) & 3;                    // cells left of 0 that align the tile to image dwords
     const int BW = min((g.aw + o + J - 1) / J * J, 64);
     const int strips_max = BW / J;
-    // one plan per band of rows, sized for the widest block and for the cropped (two-tile, 3-sum) case
+    // does any cell's patch leave the image?  Then blocks may need the validity tile and a third sum.
+    const bool any_border = g.xl0 > 0 || g.yl0 > 0 || g.xl1 < g.aw || g.yl1 < g.ah;
+    // one plan per band of rows, sized for the widest block
     const int tp_max = (strips_max * JD + G) | 1;
-    const int TR = max(1, (FAST_TILE_BYTES / 4 / 2) / tp_max);
-    const int cap_cells = FAST_ACC_BYTES / (3 * (big ? 8 : 4));
+    const int TR = max(1, (lp.tile_bytes / 4 / (any_border ? 2 : 1)) / tp_max);
+    const int cap_cells = lp.acc_bytes / ((any_border ? 3 : 2) * (big ? 8 : 4));
     bool first = true;
     int nblocks = 0;
     for (int yb = 0; yb < g.ah;) {
-        int UR = min(min(g.ph, FAST_TMPL_BYTES / 8 / G), TR);
+        int UR = max(1, min(min(g.ph, lp.tmpl_bytes / 8 / G), TR));
         int BH = max(1, min(g.ah - yb, cap_cells / (strips_max * J)));
         if (BH + UR - 1 > TR) {
             // prefer whole-template chunks: shrink the block first, then the chunk
@@ -269,15 +344,14 @@ __device__ __forceinline__ void fast_blocks(const Geo& g, const Tmpl& t, float* 
             const int bw = min(BW, g.aw - xb);
             const int strips = (bw + J - 1) / J;
             const int cx0 = max(xb, 0), cx1 = xb + bw;
-            // does the block hold cells whose patch leaves the image?
             const bool border = cx0 < g.xl0 || cx1 > g.xl1 || yb < g.yl0 || yb + BH > g.yl1;
             const int S = pick_slices(strips * BH, min(8, UR));
             if (border) {
-                if (big) fast_block<J, true, true>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
-                else fast_block<J, true, false>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
+                if (big) fast_block<J, true, true>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
+                else fast_block<J, true, false>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
             } else {
-                if (big) fast_block<J, false, true>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
-                else fast_block<J, false, false>(g, t, scores, lds, xb, yb, strips, BH, UR, S, G, first, spfull, best);
+                if (big) fast_block<J, false, true>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
+                else fast_block<J, false, false>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
             }
             first = false;
             nblocks++;
@@ -297,17 +371,17 @@ __device__ __forceinline__ int fast_cost(const Geo& g, int J) {
 
 // Score of a cell of the (single) block that is still held in the accumulators.
 __device__ __forceinline__ float fast_cell_score(const Geo& g, const lds_u8* lds, const FastState& fs,
-                                                 int x, int y, unsigned long long spfull) {
+                                                 int x, int y, const Norms& nm) {
     if (fs.J == 8) {
-        if (fs.border) return fs.big ? cell_from_acc<8, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
-                                     : cell_from_acc<8, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
-        return fs.big ? cell_from_acc<8, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
-                      : cell_from_acc<8, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
+        if (fs.border) return fs.big ? cell_from_acc<8, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
+                                     : cell_from_acc<8, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
+        return fs.big ? cell_from_acc<8, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
+                      : cell_from_acc<8, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
     }
-    if (fs.border) return fs.big ? cell_from_acc<4, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
-                                 : cell_from_acc<4, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
-    return fs.big ? cell_from_acc<4, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull)
-                  : cell_from_acc<4, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, spfull);
+    if (fs.border) return fs.big ? cell_from_acc<4, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
+                                 : cell_from_acc<4, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
+    return fs.big ? cell_from_acc<4, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
+                  : cell_from_acc<4, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
 }
 
 }  // namespace slamdev
