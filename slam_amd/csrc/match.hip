@@ -10,15 +10,22 @@
 
 using namespace slamdev;
 
+// minimum wavefronts per SIMD the register allocation must allow (caps VGPRs at 512 / this)
+#ifndef SLAM_MIN_WAVES
+#define SLAM_MIN_WAVES 3
+#endif
+
 namespace {
 
 static_assert(SLAM_WG == 64, "the search kernels assume one wavefront per workgroup");
 
 // Direct evaluation of every score cell the reference visits: one lane per cell, looping over the
-// template pixels.  Used for templates wider than the tiled core supports and as an in-GPU
-// cross-check of the tiled core (SLAM_HIP_FORCE_DIRECT=1).
-__device__ __forceinline__ void direct_cells(const Geo& g, const Tmpl& t, float* scores, unsigned long long& spfull, Norms& nm, Best& b) {
+// template pixels.  Cold path: templates too wide for the tiled core (or for the LDS it was given)
+// and the in-GPU cross-check of the tiled core (SLAM_HIP_FORCE_DIRECT=1).  Not inlined, so that it
+// does not weigh on the register allocation and code size of the tiled path.
+__device__ __noinline__ void direct_cells(Geo g, Tmpl t, float* scores, unsigned long long* spfull_out, Best* best_out) {
     const int lane = threadIdx.x;
+    unsigned long long spfull;
     {   // |patch0|^2 over the whole template (matching.cpp:63,109; template norm of matchTemplate)
         unsigned long long sp = 0;
         const int n = t.tw * t.th;
@@ -29,8 +36,8 @@ __device__ __forceinline__ void direct_cells(const Geo& g, const Tmpl& t, float*
             sp += p * p;
         }
         spfull = wave_sum_u64(sp);
-        nm = make_norms(spfull);
     }
+    Best b = {-FLT_MAX, INT_MAX};
     const int ncell = g.aw * g.ah;
     for (int c = lane; c < ncell; c += SLAM_WG) {
         const int x = c % g.aw, y = c / g.aw;
@@ -50,10 +57,13 @@ __device__ __forceinline__ void direct_cells(const Geo& g, const Tmpl& t, float*
         if (scores) scores[c] = sc;
         best_update(b, sc, c);
     }
+    *spfull_out = spfull;
+    *best_out = best_wave(b);
 }
 
 // Score-map value of cell (nx, ny) recomputed by the 64 lanes together (-1 for unvisited cells).
-__device__ __forceinline__ float cell_score_coop(const Geo& g, const Tmpl& t, int nx, int ny, unsigned long long spfull) {
+// Cold path (sub-pixel fit after a direct search).
+__device__ __noinline__ float cell_score_coop(Geo g, Tmpl t, int nx, int ny, unsigned long long spfull) {
     const int kind = classify_cell(g, nx, ny);
     if (kind == CELL_NONE) return -1.f;
     int dl = 0, dr = 0, dt = 0, db = 0;
@@ -68,91 +78,74 @@ __device__ __forceinline__ float cell_score_coop(const Geo& g, const Tmpl& t, in
                                    : score_f32(s.cc, s.si, s.sp);
 }
 
-struct CoreState {
-    Best best;                  // wave-uniform after match_core
-    unsigned long long spfull;
-    Norms nm;
-    FastState fs;
-    bool used_fast;
-};
-
-// SLAM::matchFeatureInArea for one job: score cells (tiled packed-u8 core or direct evaluation) and
-// the cv::minMaxLoc argmax.  The result is uniform over the wavefront.
+// SLAM::matchFeatureInArea for one job: score cells (tiled packed-u8 core, or direct evaluation),
+// the cv::minMaxLoc argmax (matching.cpp:221-227) and, when asked for (always, or when the response
+// is below refine_below), the sub-pixel offset of the peak: a parabola through the two horizontal /
+// vertical neighbours of the argmax cell (not in the reference).  The result is wave-uniform.
 __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
-                                              bool force_direct, CoreState& st STAMP_ARG) {
+                                              bool force_direct, bool refine_always, double refine_below STAMP_ARG) {
     Best b = {-FLT_MAX, INT_MAX};
-    st.spfull = 0;
-    st.nm = make_norms(0);
-    st.fs.single_block = false;
-    st.used_fast = !force_direct && fast_supported(g);
-    if (st.used_fast) {
-        if (fast_cost(g, 8) < fast_cost(g, 4)) fast_blocks<8>(g, t, scores, lds, lp, st.spfull, st.nm, b, st.fs STAMP_PASS);
-        else fast_blocks<4>(g, t, scores, lds, lp, st.spfull, st.nm, b, st.fs STAMP_PASS);
-    } else {
-        direct_cells(g, t, scores, st.spfull, st.nm, b);
-    }
-    b = best_wave(b);
-    st.best = b;
+    unsigned long long spfull = 0;
+    Norms nm = make_norms(0);
+    FastState fs;
+    fs.valid = false;
+    const bool use_fast = !force_direct && fast_supported(g, lp);
+    if (use_fast) fast_search(g, t, scores, lds, lp, refine_always, refine_below, spfull, nm, b, fs STAMP_PASS);
+    else direct_cells(g, t, scores, &spfull, &b);
     STAMP(20);
     CoreOut o;
     o.dx = 0.f; o.dy = 0.f;
     if (b.idx == INT_MAX) {      // nothing compared greater than -FLT_MAX: every cell is NaN
         o.x = -1 + g.ax; o.y = -1 + g.ay; o.response = 0.f;
-    } else {
-        o.x = b.idx % g.aw + g.ax; o.y = b.idx / g.aw + g.ay; o.response = b.v;
+        return o;
     }
-    return o;
-}
+    const int ly = b.idx / g.aw, lx = b.idx - ly * g.aw;
+    o.x = lx + g.ax; o.y = ly + g.ay; o.response = b.v;
+    if (!(refine_always || (double)b.v < refine_below)) return o;
 
-// Sub-pixel offset of the peak: parabola through the two horizontal / vertical neighbours of the
-// argmax cell (not in the reference).  Neighbour scores come from the block accumulators when the
-// whole map was one block of the tiled core, otherwise they are recomputed.
-__device__ __forceinline__ void subpixel(const Geo& g, const Tmpl& t, const lds_u8* lds, const CoreState& st, CoreOut& o) {
-    o.dx = 0.f; o.dy = 0.f;
-    if (st.best.idx == INT_MAX) return;
-    const int lx = st.best.idx % g.aw, ly = st.best.idx / g.aw;
-    const float s = st.best.v;
-    float nb[4];
-    bool ok[4];
-    if (st.used_fast && st.fs.single_block) {
-        // lanes 0..3 each read one neighbour's sums from the block accumulators
-        const int n = threadIdx.x & 3;
-        const int nx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0);
-        const int ny = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
-        const bool in = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
-        const float v = in ? fast_cell_score(g, lds, st.fs, nx, ny, st.nm) : -1.f;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { nb[k] = __shfl(v, k, 64); ok[k] = __shfl((int)in, k, 64) != 0; }
+    // the four neighbours of the peak: lanes 0..3 each fetch one
+    const int n = threadIdx.x & 3;
+    const int nx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0);
+    const int ny = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
+    const bool in = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
+    float v = -1.f;
+    if (use_fast) {
+        if (in) v = cell_from_acc(g, lds, fs.ba, fs.big, nx, ny, nm);
     } else {
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-            const int nx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0);
-            const int ny = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
-            ok[n] = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;
-            nb[n] = ok[n] ? cell_score_coop(g, t, nx, ny, st.spfull) : -1.f;
+        for (int k = 0; k < 4; k++) {                      // cooperative: every lane takes part in each cell
+            const int kx = lx + (k == 0 ? -1 : k == 1 ? 1 : 0), ky = ly + (k == 2 ? -1 : k == 3 ? 1 : 0);
+            if (kx >= 0 && ky >= 0 && kx < g.aw && ky < g.ah) {
+                const float s = cell_score_coop(g, t, kx, ky, spfull);
+                if (n == k) v = s;
+            }
         }
     }
-    if (ok[0] && ok[1] && nb[0] != -1.f && nb[1] != -1.f && nb[0] == nb[0] && nb[1] == nb[1]) {
-        const float d2 = __fsub_rn(__fadd_rn(nb[0], nb[1]), __fmul_rn(2.0f, s));
+    const float sl = __shfl(v, 0, 64), sr = __shfl(v, 1, 64), su = __shfl(v, 2, 64), sd = __shfl(v, 3, 64);
+    const bool okl = __shfl((int)in, 0, 64) != 0, okr = __shfl((int)in, 1, 64) != 0;
+    const bool oku = __shfl((int)in, 2, 64) != 0, okd = __shfl((int)in, 3, 64) != 0;
+    const float s = b.v;
+    if (okl && okr && sl != -1.f && sr != -1.f && sl == sl && sr == sr) {
+        const float d2 = __fsub_rn(__fadd_rn(sl, sr), __fmul_rn(2.0f, s));
         if (d2 < 0.f) {
-            const float q = __fdiv_rn(__fsub_rn(nb[0], nb[1]), __fmul_rn(2.0f, d2));
+            const float q = __fdiv_rn(__fsub_rn(sl, sr), __fmul_rn(2.0f, d2));
             o.dx = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
         }
     }
-    if (ok[2] && ok[3] && nb[2] != -1.f && nb[3] != -1.f && nb[2] == nb[2] && nb[3] == nb[3]) {
-        const float d2 = __fsub_rn(__fadd_rn(nb[2], nb[3]), __fmul_rn(2.0f, s));
+    if (oku && okd && su != -1.f && sd != -1.f && su == su && sd == sd) {
+        const float d2 = __fsub_rn(__fadd_rn(su, sd), __fmul_rn(2.0f, s));
         if (d2 < 0.f) {
-            const float q = __fdiv_rn(__fsub_rn(nb[2], nb[3]), __fmul_rn(2.0f, d2));
+            const float q = __fdiv_rn(__fsub_rn(su, sd), __fmul_rn(2.0f, d2));
             o.dy = q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
         }
     }
+    return o;
 }
 
 __device__ __forceinline__ bool span_ok(long long off, long long len, unsigned long long total) {
     return off >= 0 && len >= 0 && (unsigned long long)off <= total && (unsigned long long)len <= total - (unsigned long long)off;
 }
 
-__global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes, float* scores,
                                                         unsigned long long scores_len,
@@ -200,14 +193,13 @@ __global__ __launch_bounds__(SLAM_WG, 4) void match_kernel(slam_pyr_dev pyr, con
     t.mask = job.pmask_off != -1 ? blob + job.pmask_off : nullptr;
     t.srcw = job.pw; t.srch = job.ph; t.tw = job.pw; t.th = job.ph; t.resized = false;
     t.scale_x = 1.0; t.scale_y = 1.0;
-    CoreState st;
+    t.limit = blob + blob_bytes;
     STAMP_DECL;
-    CoreOut o = match_core(g, t, sc, lds, plan, force_direct != 0, st STAMP_PASS);
-    subpixel(g, t, lds, st, o);
+    const CoreOut o = match_core(g, t, sc, lds, plan, force_direct != 0, true, 0.0 STAMP_PASS);
     if (threadIdx.x == 0) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
 }
 
-__global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
                                                         slam_track_result* __restrict__ out, int force_direct, int lds_total) {
@@ -235,6 +227,7 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
     t.patch = blob + job.proj_off; t.mask = blob + job.mask_off;
     t.srcw = job.projw; t.srch = job.projh;
     t.scale_x = 1.0; t.scale_y = 1.0;
+    t.limit = blob + blob_bytes;
 
     STAMP_DECL;
     STAMP(1);
@@ -279,12 +272,10 @@ __global__ __launch_bounds__(SLAM_WG, 4) void track_kernel(slam_pyr_dev pyr, con
         STAMP(2);
         if (g.reject) { response = -1.f; }       // matching.cpp:26-30
         else {
-            CoreState st;
-            CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, st STAMP_PASS);
-            mx = o.x; my = o.y; response = o.response;
-            // feature.cpp:151-152; the sub-pixel fit is only reported for the last level run
-            const bool last = (i == 0) || ((double)response < __dmul_rn(0.67, (double)job.threshold));
-            if (last) { subpixel(g, t, lds, st, o); sdx = o.dx; sdy = o.dy; }
+            // feature.cpp:151-152: the level that ends the walk also reports the sub-pixel fit
+            const double stop_below = __dmul_rn(0.67, (double)job.threshold);
+            const CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, i == 0, stop_below STAMP_PASS);
+            mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
             STAMP(21);
         }
         tx = __fmul_rn((float)mx, sub);          // feature.cpp:150

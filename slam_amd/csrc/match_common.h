@@ -186,7 +186,22 @@ struct Tmpl {
     int tw, th;               // size at this level
     bool resized;
     double scale_x, scale_y;  // cv::resize's scale = 1 / ((double)dsize / ssize), when resized
+    const uint8_t* limit;     // end of the buffer patch and mask live in (no byte at or past it is read)
 };
+
+// Four consecutive bytes at p (any alignment) as one little-endian dword; bytes at or beyond
+// `limit` read as 0.
+__device__ __forceinline__ unsigned load4(const uint8_t* p, const uint8_t* limit) {
+    unsigned v = 0;
+    if (p + 4 <= limit) {
+        __builtin_memcpy(&v, p, 4);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if (p + b < limit) v |= (unsigned)p[b] << (8 * b);
+    }
+    return v;
+}
 
 // cv::resize's scale factor for one axis
 __device__ __forceinline__ double resize_scale(int ssize, int dsize) {

@@ -10,20 +10,21 @@
 //           is a multiple of 4 in IMAGE columns so rows are fetched as aligned dwords
 //   vtile : 0xFF where the tile pixel is inside the image (only for blocks with cropped cells)
 //
-// Work split: the block's cells are cut into strips of J (4 or 8) consecutive cells of one row; a
-// task is one strip x one slice of the chunk's template rows, and the 64 lanes walk the task list.
-// Per 4-pixel group a lane forms, for each of its J cells, the cell's 4 image pixels with one
-// v_perm_b32 (byte alignment and patch mask folded into one selector) and feeds two v_dot4_u32_u8
-// (CC += <Im,P0>, SI += <Im,Im>); blocks with cropped cells add SPcrop += <P0 & valid, P0>.
+// Work split: the block's cells are cut into strips of 4 consecutive cells of one row; a task is one
+// strip x one slice of the chunk's template rows, and the 64 lanes walk the task list.  Per 4-pixel
+// group a lane forms each cell's 4 image pixels with v_alignbyte_b32, masks them, and feeds two
+// v_dot4_u32_u8 (CC += <I,P0>, SI += <Im,Im>); blocks with cropped cells add SPcrop += <P0&valid,P0>.
 // Every sum is an exact integer, so the scores are bit-identical to a scalar evaluation.
+//
+// The code is written once (no per-mode copies outside the inner loop): the search kernels are
+// instruction-cache bound if each mode gets its own copy of the staging and scoring code.
 #pragma once
 
 #include "match_common.h"
 
 #define FAST_LDS_DEFAULT (16 * 1024)
-#define FAST_LDS_MIN (4 * 1024)
-#define FAST_LDS_MAX (64 * 1024)
-#define FAST_MAX_G 96         // template width up to 384 pixels; wider ones use direct evaluation
+#define FAST_J 4
+#define FAST_MAX_G 128        // template width up to 512 pixels; wider ones use direct evaluation
 
 namespace slamdev {
 
@@ -46,85 +47,74 @@ __device__ __forceinline__ LdsPlan make_lds_plan(int lds_total) {
     return p;
 }
 
-// What the tiled core leaves behind for the sub-pixel fit when the whole score map was one block.
-struct FastState {
-    bool single_block;
-    bool border, big;
-    int J, xb, yb, strips, bh;
+struct BlockArgs {
+    int xb, yb, strips, bh;
+    bool border;
 };
 
-__device__ __forceinline__ unsigned bfi32(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
-
-// Accumulate template rows [ub, ue) (chunk-relative) for the J cells of one strip.  Tile row r
+// Accumulate template rows [ub, ue) (chunk-relative) for the 4 cells of one strip.  Tile row r
 // holds image row (first image row of the tile) + r and the cell row `row` is relative to the
 // block, so template row u of that cell lies in tile row row + u.
-template <int J, bool BORDER>
+template <bool BORDER>
 __device__ __forceinline__ void strip_accumulate(const lds_u32* tile, const lds_u32* vtile, int tp,
                                                  const lds_u64* tmpl, int G, int ub, int ue, int row, int strip,
-                                                 unsigned (&cc)[J], unsigned (&si)[J], unsigned (&sp)[J]) {
-    constexpr int JD = J / 4;
+                                                 unsigned (&cc)[4], unsigned (&si)[4], unsigned (&sp)[4]) {
     for (int u = ub; u < ue; ++u) {
-        const int tofs = (row + u) * tp + strip * JD;
+        const int tofs = (row + u) * tp + strip;
         const lds_u32* tr = tile + tofs;
         const lds_u32* vr = vtile + tofs;
         const lds_u64* pr = tmpl + u * G;
-        unsigned d0 = tr[0], d1 = (JD == 2) ? tr[1] : 0u;
-        unsigned v0 = 0, v1 = 0;
-        if (BORDER) { v0 = vr[0]; v1 = (JD == 2) ? vr[1] : 0u; }
+        unsigned d0 = tr[0];
+        unsigned v0 = BORDER ? vr[0] : 0u;
 #pragma unroll 2
         for (int g = 0; g < G; ++g) {
-            const unsigned dn = tr[g + JD];
+            const unsigned dn = tr[g + 1];
             const unsigned long long pm = pr[g];
             const unsigned P0 = (unsigned)pm, M = (unsigned)(pm >> 32);
-            unsigned sel[4];
+            const unsigned vn = BORDER ? vr[g + 1] : 0u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) sel[k] = bfi32(M, 0x03020100u + 0x01010101u * (unsigned)k, 0x0C0C0C0Cu);
-            unsigned vn = 0;
-            if (BORDER) vn = vr[g + JD];
-#pragma unroll
-            for (int k = 0; k < J; k++) {
-                const unsigned hi = (JD == 1) ? dn : (k < 4 ? d1 : dn);
-                const unsigned lo = (JD == 1) ? d0 : (k < 4 ? d0 : d1);
-                const unsigned w = __builtin_amdgcn_perm(hi, lo, sel[k & 3]);
-                cc[k] = __builtin_amdgcn_udot4(w, P0, cc[k], false);
-                si[k] = __builtin_amdgcn_udot4(w, w, si[k], false);
+            for (int k = 0; k < 4; k++) {
+                const unsigned w = (k == 0) ? d0 : __builtin_amdgcn_alignbyte(dn, d0, k);
+                const unsigned wm = w & M;
+                cc[k] = __builtin_amdgcn_udot4(w, P0, cc[k], false);      // P0 is already masked
+                si[k] = __builtin_amdgcn_udot4(wm, wm, si[k], false);
                 if (BORDER) {
-                    const unsigned vhi = (JD == 1) ? vn : (k < 4 ? v1 : vn);
-                    const unsigned vlo = (JD == 1) ? v0 : (k < 4 ? v0 : v1);
-                    const unsigned vm = __builtin_amdgcn_perm(vhi, vlo, sel[k & 3]);
+                    const unsigned vm = (k == 0) ? v0 : __builtin_amdgcn_alignbyte(vn, v0, k);
                     sp[k] = __builtin_amdgcn_udot4(P0 & vm, P0, sp[k], false);
                 }
             }
-            if (JD == 1) { d0 = dn; v0 = vn; } else { d0 = d1; d1 = dn; v0 = v1; v1 = vn; }
+            d0 = dn; v0 = vn;
         }
     }
 }
 
-__device__ __forceinline__ float finalize_cell(const Geo& g, int x, int y, unsigned long long CC,
-                                               unsigned long long SI, unsigned long long SPc, const Norms& nm) {
-    const int kind = classify_cell(g, x, y);
-    if (kind == CELL_NONE) return -1.f;                    // matching.cpp:53
-    if (kind == CELL_MT) return score_mt_n(CC, SI, nm.tn);
-    if (kind == CELL_F32_FULL) return score_f32_n(CC, SI, nm.p2f);
-    return score_f32(CC, SI, SPc);
-}
-
-template <bool BIG>
-__device__ __forceinline__ unsigned long long acc_read(const lds_u8* acc, int i) {
-    if (BIG) return reinterpret_cast<const lds_u64*>(acc)[i];
+__device__ __forceinline__ unsigned long long acc_read(const lds_u8* acc, int i, bool big) {
+    if (big) return reinterpret_cast<const lds_u64*>(acc)[i];
     return reinterpret_cast<const lds_u32*>(acc)[i];
 }
 
-// Score of block cell (x,y) from the block's accumulators (x,y must be cells of that block).
-template <int J, bool BORDER, bool BIG>
-__device__ __forceinline__ float cell_from_acc(const Geo& g, const lds_u8* acc, int xb, int yb, int strips,
+// Score-map value of block cell (x,y) from the block's accumulators (-1 for cells the reference
+// never visits).  One sqrt(double) of the window energy serves all three formulas.
+__device__ __forceinline__ float cell_from_acc(const Geo& g, const lds_u8* acc, const BlockArgs& ba, bool big,
                                                int x, int y, const Norms& nm) {
-    constexpr int AW = BORDER ? 3 : 2;
-    const int c = ((y - yb) * strips) * J + (x - xb);      // (row*strips + strip)*J + k
-    const unsigned long long CC = acc_read<BIG>(acc, c * AW + 0);
-    const unsigned long long SI = acc_read<BIG>(acc, c * AW + 1);
-    const unsigned long long SP = BORDER ? acc_read<BIG>(acc, c * AW + 2) : 0ull;
-    return finalize_cell(g, x, y, CC, SI, SP, nm);
+    const int kind = classify_cell(g, x, y);
+    if (kind == CELL_NONE) return -1.f;                    // matching.cpp:53
+    const int aw = ba.border ? 3 : 2;
+    const int c = ((y - ba.yb) * ba.strips) * FAST_J + (x - ba.xb);      // (row*strips + strip)*4 + k
+    const unsigned long long CC = acc_read(acc, c * aw + 0, big);
+    const unsigned long long SI = acc_read(acc, c * aw + 1, big);
+    const double si = __dsqrt_rn((double)SI);
+    if (kind == CELL_MT) {                                 // cv::matchTemplate(CV_TM_CCORR_NORMED), matching.cpp:152
+        double num = (double)CC;
+        const double t = __dmul_rn(si, nm.tn);
+        if (fabs(num) < t) num = __ddiv_rn(num, t);
+        else if (fabs(num) < __dmul_rn(t, 1.125)) num = num > 0 ? 1.0 : -1.0;
+        else num = 0.0;
+        return (float)num;
+    }
+    float p2 = nm.p2f;                                     // matching.cpp:63,109
+    if (kind == CELL_F32_CROP) p2 = (float)__dsqrt_rn((double)acc_read(acc, c * aw + 2, big));   // matching.cpp:99
+    return __fdiv_rn((float)(double)CC, __fmul_rn((float)si, p2));       // matching.cpp:70-72
 }
 
 // Lane -> (row, column) walk over a rows x width rectangle without per-element divisions:
@@ -134,12 +124,19 @@ struct Walk2D {
     int r0, c0, rstep, cstep;
 };
 
+// floor(n / d) for 0 <= n < 2^19, d >= 1 through one v_rcp_f32 (1 ulp): (n + 0.5) / d is at least
+// 0.5/d away from an integer, far more than the float rounding error at these magnitudes.
+__device__ __forceinline__ int small_div(int n, int d) {
+    return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
+
 __device__ __forceinline__ Walk2D make_walk(int width, int rows) {
     Walk2D w;
     const int lane = threadIdx.x;
     if (width <= SLAM_WG) {
-        const int per = SLAM_WG / width;                   // rows handled per pass
-        const int lr = lane / width;
+        const float rw = __builtin_amdgcn_rcpf((float)width);
+        const int per = (int)(64.5f * rw);                               // rows handled per pass
+        const int lr = (int)(((float)lane + 0.5f) * rw);
         w.c0 = lane - lr * width;
         w.r0 = lr < per ? lr : rows;                       // surplus lanes do nothing
         w.rstep = per;
@@ -150,32 +147,28 @@ __device__ __forceinline__ Walk2D make_walk(int width, int rows) {
     return w;
 }
 
-// One block of cells [xb, xb + strips*J) x [yb, yb+bh) (xb may be < 0: columns left of 0 and right
-// of aw are padding).  Adds the block's scores to the running argmax.
-template <int J, bool BORDER, bool BIG>
+// One block of cells [xb, xb + 4*strips) x [yb, yb+bh) (xb may be < 0: columns left of 0 and right
+// of aw are padding): sums into acc, then (update) scores into the running argmax / score map.
 __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
-                                           int xb, int yb, int strips, int bh, int UR, int S, int G,
-                                           bool first_block, unsigned long long& spfull, Norms& nm, Best& best STAMP_ARG) {
+                                           const BlockArgs& ba, int UR, int S, int G, bool big, bool first_block,
+                                           bool update, unsigned long long& spfull, Norms& nm, Best& best STAMP_ARG) {
     const int lane = threadIdx.x;
-    constexpr int JD = J / 4;
-    constexpr int AW = BORDER ? 3 : 2;
+    const int AW = ba.border ? 3 : 2;
     lds_u8* acc = lds;
     lds_u64* tmpl = reinterpret_cast<lds_u64*>(lds + lp.acc_bytes);
     lds_u32* tile = reinterpret_cast<lds_u32*>(lds + lp.acc_bytes + lp.tmpl_bytes);
-    const int tp = (strips * JD + G) | 1;                  // odd dword pitch: rows spread over the banks
-    const int trows_max = (lp.tile_bytes / 4 / (BORDER ? 2 : 1)) / tp;
-    lds_u32* vtile = tile + trows_max * tp;
-    const int width = strips * J;                          // cells per block row, <= 64
+    const int strips = ba.strips, bh = ba.bh, xb = ba.xb, yb = ba.yb;
+    const int tp = (strips + G) | 1;                       // odd dword pitch: rows spread over the banks
+    const int trows_cap = small_div(lp.tile_bytes / 4 / (ba.border ? 2 : 1), tp);
+    lds_u32* vtile = tile + trows_cap * tp;
     const int units = strips * bh;
     const int ntask = units * S;
-    const int ncell = units * J;
     const int ix0 = g.x0 + xb;                             // image column of tile column 0 (multiple of 4)
     const bool aligned = ((reinterpret_cast<unsigned long long>(g.im) | (unsigned long long)g.ipitch) & 3ull) == 0;
-    const unsigned rcpS = rcp_u32((unsigned)S), rcpStrips = rcp_u32((unsigned)strips);
     unsigned long long sp_part = 0;
 
-    __syncthreads();                                       // the previous block's finalize has read acc
-    for (int i = lane; i < ncell * AW * (BIG ? 2 : 1); i += SLAM_WG) reinterpret_cast<lds_u32*>(acc)[i] = 0;
+    __syncthreads();                                       // the previous block's readers of acc are done
+    for (int i = lane; i < units * FAST_J * AW * (big ? 2 : 1); i += SLAM_WG) reinterpret_cast<lds_u32*>(acc)[i] = 0;
 
     for (int u0 = 0; u0 < g.ph; u0 += UR) {
         const int ur = min(UR, g.ph - u0);
@@ -184,39 +177,42 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
         {
             const Walk2D w = make_walk(G, ur);
-            for (int u = w.r0; u < ur; u += w.rstep)
-                for (int gg = w.c0; gg < G; gg += w.cstep) {
-                    unsigned P0 = 0, M = 0;
-                    if (!t.resized) {
+            for (int gg = w.c0; gg < G; gg += w.cstep) {
+                const int nb = min(4, g.pw - gg * 4);      // pixels of this group inside the template
+                const unsigned keep = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                if (!t.resized) {
+                    for (int u = w.r0; u < ur; u += w.rstep) {
                         const long long o = (long long)(u0 + u) * t.srcw + gg * 4;
+                        const unsigned P = load4(t.patch + o, t.limit);
+                        const unsigned Mraw = t.mask ? load4(t.mask + o, t.limit) : 0x01010101u;
+                        // per byte: non-zero -> 0xFF
+                        const unsigned nz = (((Mraw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | Mraw) & 0x80808080u;
+                        const unsigned M = ((nz >> 7) * 0xFFu) & keep;
+                        const unsigned P0 = P & M;
+                        sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
+                        tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
+                    }
+                } else {
+                    int sx[4], a0[4], a1[4];               // the column taps do not depend on the row
 #pragma unroll
-                        for (int b = 0; b < 4; b++)
-                            if (gg * 4 + b < g.pw) {
-                                unsigned p = t.patch[o + b];
-                                const unsigned m = t.mask ? (unsigned)(t.mask[o + b] != 0) : 1u;
-                                p *= m;
-                                P0 |= p << (8 * b);
-                                M |= (m ? 0xFFu : 0u) << (8 * b);
-                                if (first_block) sp_part += p * p;
-                            }
-                    } else {
+                    for (int b = 0; b < 4; b++) resize_tap(min(gg * 4 + b, g.pw - 1), t.scale_x, t.srcw, true, sx[b], a0[b], a1[b]);
+                    for (int u = w.r0; u < ur; u += w.rstep) {
                         int sy, b0, b1;
                         resize_tap(u0 + u, t.scale_y, t.srch, false, sy, b0, b1);
+                        unsigned P0 = 0, M = 0;
 #pragma unroll
-                        for (int b = 0; b < 4; b++)
-                            if (gg * 4 + b < g.pw) {
-                                int sx, a0, a1;
-                                resize_tap(gg * 4 + b, t.scale_x, t.srcw, true, sx, a0, a1);
-                                unsigned p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, false);
-                                const unsigned m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, true) != 0) : 1u;
-                                p *= m;
-                                P0 |= p << (8 * b);
-                                M |= (m ? 0xFFu : 0u) << (8 * b);
-                                if (first_block) sp_part += p * p;
-                            }
+                        for (int b = 0; b < 4; b++) {
+                            const unsigned m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx[b], a0[b], a1[b], sy, b0, b1, true) != 0) : 1u;
+                            const unsigned p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx[b], a0[b], a1[b], sy, b0, b1, false) * m;
+                            P0 |= p << (8 * b);
+                            M |= (m ? 0xFFu : 0u) << (8 * b);
+                        }
+                        P0 &= keep; M &= keep;
+                        sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
+                        tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
                     }
-                    tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
                 }
+            }
         }
         STAMP(11);
         // ---- stage the image tile (and its validity) --------------------------------------------
@@ -244,7 +240,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
                         }
                     }
                     tile[r * tp + c] = px;
-                    if (BORDER) vtile[r * tp + c] = vv;
+                    if (ba.border) vtile[r * tp + c] = vv;
                 }
             }
         }
@@ -252,26 +248,25 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         STAMP(12);
         // ---- accumulate: the lanes walk the (strip, row-slice) tasks -----------------------------
         for (int task = lane; task < ntask; task += SLAM_WG) {
-            const int unit = (int)div_rcp((unsigned)task, (unsigned)S, rcpS), slice = task - unit * S;
-            const int row = (int)div_rcp((unsigned)unit, (unsigned)strips, rcpStrips), strip = unit - row * strips;
-            const int ub = (slice * ur) / S, ue = ((slice + 1) * ur) / S;
-            unsigned cc[J], si[J], sp[J];
+            const int unit = small_div(task, S), slice = task - unit * S;
+            const int row = small_div(unit, strips), strip = unit - row * strips;
+            const int ub = small_div(slice * ur, S), ue = small_div((slice + 1) * ur, S);
+            unsigned cc[4] = {0, 0, 0, 0}, si[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
+            if (ba.border) strip_accumulate<true>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
+            else strip_accumulate<false>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
 #pragma unroll
-            for (int k = 0; k < J; k++) { cc[k] = 0; si[k] = 0; sp[k] = 0; }
-            strip_accumulate<J, BORDER>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
-#pragma unroll
-            for (int k = 0; k < J; k++) {
-                const int a = (unit * J + k) * AW;
-                if (BIG) {
+            for (int k = 0; k < 4; k++) {
+                const int a = (unit * FAST_J + k) * AW;
+                if (big) {
                     lds_u64* a64 = reinterpret_cast<lds_u64*>(acc);
                     __hip_atomic_fetch_add(a64 + a, (unsigned long long)cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(a64 + a + 1, (unsigned long long)si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (BORDER) __hip_atomic_fetch_add(a64 + a + 2, (unsigned long long)sp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ba.border) __hip_atomic_fetch_add(a64 + a + 2, (unsigned long long)sp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
                     lds_u32* a32 = reinterpret_cast<lds_u32*>(acc);
                     __hip_atomic_fetch_add(a32 + a, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(a32 + a + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (BORDER) __hip_atomic_fetch_add(a32 + a + 2, sp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ba.border) __hip_atomic_fetch_add(a32 + a + 2, sp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -283,14 +278,14 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
     }
     __syncthreads();
 
-    // ---- finalize: scores of the block's cells, running argmax -----------------------------------
-    {
-        const Walk2D w = make_walk(width, bh);
+    // ---- scores of the block's cells, running argmax ---------------------------------------------
+    if (update) {
+        const Walk2D w = make_walk(strips * FAST_J, bh);
         const int x = xb + w.c0;
         if (x >= 0 && x < g.aw)
             for (int r = w.r0; r < bh; r += w.rstep) {
                 const int y = yb + r;
-                const float sc = cell_from_acc<J, BORDER, BIG>(g, acc, xb, yb, strips, x, y, nm);
+                const float sc = cell_from_acc(g, acc, ba, big, x, y, nm);
                 const int idx = y * g.aw + x;
                 if (scores) scores[idx] = sc;
                 best_update(best, sc, idx);
@@ -299,89 +294,92 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
     STAMP(14);
 }
 
-// True when the tiled core can run this job; otherwise the caller uses direct evaluation.
-__device__ __forceinline__ bool fast_supported(const Geo& g) {
-    return (g.pw + 3) / 4 <= FAST_MAX_G;
+// True when the tiled core can run this job with the LDS it was given: the template must be at most
+// 4*FAST_MAX_G wide and three tile rows (the peak's neighbourhood) must fit next to one template row
+// in the cropped (two-tile) case.  Otherwise the caller uses direct evaluation.
+__device__ __forceinline__ bool fast_supported(const Geo& g, const LdsPlan& lp) {
+    const int G = (g.pw + 3) >> 2;
+    return G <= FAST_MAX_G && lp.tile_bytes / 8 >= 3 * ((16 + G) | 1) && lp.tmpl_bytes / 8 >= G;
 }
 
-// Row slices per strip: the S in [1, smax] that best fills the 64 lanes with strip x slice tasks.
-__device__ __forceinline__ int pick_slices(int units, int smax) {
-    int best_s = 1, best_u = 0;
-    for (int s = 1; s <= smax; s++) {
-        const int n = units * s;
-        const int u = n * 1000 / ((n + SLAM_WG - 1) / SLAM_WG * SLAM_WG);   // lane utilisation, per mille
-        if (u > best_u + 30) { best_u = u; best_s = s; }
+// Row slices per strip: the S in [1, 8] (S <= rows) that minimises passes x rows-per-slice when
+// units x S tasks are dealt to the 64 lanes.
+__device__ __forceinline__ int pick_slices(int units, int rows) {
+    int best_s = 1, best_c = 1 << 30;
+#pragma unroll
+    for (int s = 1; s <= 8; s++) {
+        if (s > rows) break;
+        const int passes = (units * s + SLAM_WG - 1) >> 6;
+        const int c = passes * ((rows + s - 1) / s + 1);   // +1: the per-task flush
+        if (c < best_c) { best_c = c; best_s = s; }
     }
     return best_s;
 }
 
-template <int J>
-__device__ __forceinline__ void fast_blocks(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
-                                            unsigned long long& spfull, Norms& nm, Best& best, FastState& fs STAMP_ARG) {
-    constexpr int JD = J / 4;
-    const int G = (g.pw + 3) / 4;
+// What is left in the accumulators after fast_search: the block that holds the peak's neighbours.
+struct FastState {
+    bool valid;
+    bool big;
+    BlockArgs ba;
+};
+
+// Searches the whole score map block by block.  On return `best` is the wave-uniform argmax and,
+// when a refinement was asked for (or the map was a single block), fs describes a block in the accumulators that
+// contains the peak and its four neighbours (for the sub-pixel fit).
+__device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
+                                            bool refine_always, double refine_below, unsigned long long& spfull,
+                                            Norms& nm, Best& best, FastState& fs STAMP_ARG) {
+    const int G = (g.pw + 3) >> 2;
     const bool big = (long long)g.pw * g.ph > 66051;       // 66051 * 255^2 < 2^32: beyond it sums need 64 bits
-    const int o = ((g.x0 % 4) + 4) & 3;                    // cells left of 0 that align the tile to image dwords
-    const int BW = min((g.aw + o + J - 1) / J * J, 64);
-    const int strips_max = BW / J;
+    const int o = g.x0 & 3;                                // cells left of 0 that align the tile to image dwords
+    const int BW = min((g.aw + o + 3) & ~3, 64);
+    const int strips_max = BW >> 2;
     // does any cell's patch leave the image?  Then blocks may need the validity tile and a third sum.
     const bool any_border = g.xl0 > 0 || g.yl0 > 0 || g.xl1 < g.aw || g.yl1 < g.ah;
-    // one plan per band of rows, sized for the widest block
-    const int tp_max = (strips_max * JD + G) | 1;
-    const int TR = max(1, (lp.tile_bytes / 4 / (any_border ? 2 : 1)) / tp_max);
-    const int cap_cells = lp.acc_bytes / ((any_border ? 3 : 2) * (big ? 8 : 4));
-    bool first = true;
-    int nblocks = 0;
-    for (int yb = 0; yb < g.ah;) {
-        int UR = max(1, min(min(g.ph, lp.tmpl_bytes / 8 / G), TR));
-        int BH = max(1, min(g.ah - yb, cap_cells / (strips_max * J)));
-        if (BH + UR - 1 > TR) {
-            // prefer whole-template chunks: shrink the block first, then the chunk
-            if (TR - UR + 1 >= 4 || UR == 1) BH = max(1, min(BH, TR - UR + 1));
-            else { UR = max(1, TR / 2); BH = max(1, min(BH, TR - UR + 1)); }
-        }
-        for (int xb = -o; xb < g.aw; xb += BW) {
-            const int bw = min(BW, g.aw - xb);
-            const int strips = (bw + J - 1) / J;
-            const int cx0 = max(xb, 0), cx1 = xb + bw;
-            const bool border = cx0 < g.xl0 || cx1 > g.xl1 || yb < g.yl0 || yb + BH > g.yl1;
-            const int S = pick_slices(strips * BH, min(8, UR));
-            if (border) {
-                if (big) fast_block<J, true, true>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
-                else fast_block<J, true, false>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
+    const int tp_max = (strips_max + G) | 1;
+    const int TR = max(1, small_div(lp.tile_bytes / 4 / (any_border ? 2 : 1), tp_max));
+    const int cap_rows = max(1, small_div(lp.acc_bytes / ((any_border ? 3 : 2) * (big ? 8 : 4)), BW));
+    int UR = max(1, min(min(g.ph, small_div(lp.tmpl_bytes / 8, G)), TR));
+    int BH = min(g.ah, cap_rows);
+    if (BH + UR - 1 > TR) {
+        // prefer whole-template chunks: shrink the block first, then the chunk
+        if (TR - UR + 1 >= 4 || UR == 1) BH = max(1, min(BH, TR - UR + 1));
+        else { UR = max(1, TR / 2); BH = max(1, min(BH, TR - UR + 1)); }
+    }
+    fs.valid = false; fs.big = big;
+    bool first = true, refine = false;
+    int nblocks = 0, yb = 0, xb = -o;
+    while (true) {
+        BlockArgs ba;
+        if (!refine) {
+            if (yb >= g.ah) {                              // scan finished: the argmax is known
+                best = best_wave(best);
+                if (nblocks == 1) { fs.valid = true; break; }
+                if (best.idx == INT_MAX || !(refine_always || (double)best.v < refine_below)) break;
+                // multi-block map: recompute the 3x3 cells around the peak into the accumulators
+                const int ly = best.idx / g.aw, lx = best.idx - ly * g.aw;
+                refine = true;
+                ba.xb = ((max(lx - 1, 0) + o) & ~3) - o;
+                ba.strips = ((min(lx + 1, g.aw - 1) - ba.xb) >> 2) + 1;
+                ba.yb = max(ly - 1, 0);
+                ba.bh = min(ly + 1, g.ah - 1) - ba.yb + 1;
             } else {
-                if (big) fast_block<J, false, true>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
-                else fast_block<J, false, false>(g, t, scores, lds, lp, xb, yb, strips, BH, UR, S, G, first, spfull, nm, best STAMP_PASS);
+                ba.xb = xb; ba.yb = yb;
+                ba.strips = (min(BW, g.aw - xb) + 3) >> 2;
+                ba.bh = min(BH, g.ah - yb);
+                xb += BW;
+                if (xb >= g.aw) { xb = -o; yb += BH; }
             }
-            first = false;
-            nblocks++;
-            fs.border = border; fs.big = big; fs.J = J; fs.xb = xb; fs.yb = yb; fs.strips = strips; fs.bh = BH;
         }
-        yb += BH;
+        ba.border = max(ba.xb, 0) < g.xl0 || min(ba.xb + ba.strips * FAST_J, g.aw) > g.xl1 || ba.yb < g.yl0 || ba.yb + ba.bh > g.yl1;
+        const int URb = refine ? max(1, min(UR, TR - ba.bh + 1)) : UR;     // the 3-row refine block must fit the tile
+        const int S = pick_slices(ba.strips * ba.bh, URb);
+        fast_block(g, t, refine ? nullptr : scores, lds, lp, ba, URb, S, G, big, first, !refine, spfull, nm, best STAMP_PASS);
+        first = false;
+        nblocks++;
+        fs.ba = ba;
+        if (refine) { fs.valid = true; break; }
     }
-    fs.single_block = nblocks == 1;
-}
-
-// VALU operations per useful cell and 4-pixel group for strips of J cells (4 selector ops + 3 per cell)
-__device__ __forceinline__ int fast_cost(const Geo& g, int J) {
-    const int o = ((g.x0 % 4) + 4) & 3;
-    const int strips = (g.aw + o + J - 1) / J;
-    return (4 + 3 * J) * strips;
-}
-
-// Score of a cell of the (single) block that is still held in the accumulators.
-__device__ __forceinline__ float fast_cell_score(const Geo& g, const lds_u8* lds, const FastState& fs,
-                                                 int x, int y, const Norms& nm) {
-    if (fs.J == 8) {
-        if (fs.border) return fs.big ? cell_from_acc<8, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
-                                     : cell_from_acc<8, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
-        return fs.big ? cell_from_acc<8, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
-                      : cell_from_acc<8, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
-    }
-    if (fs.border) return fs.big ? cell_from_acc<4, true, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
-                                 : cell_from_acc<4, true, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
-    return fs.big ? cell_from_acc<4, false, true>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm)
-                  : cell_from_acc<4, false, false>(g, lds, fs.xb, fs.yb, fs.strips, x, y, nm);
 }
 
 }  // namespace slamdev
