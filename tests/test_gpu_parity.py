@@ -278,3 +278,102 @@ def test_get_sorted_keypoints_matches_oracle(ctx, oracle):
     # an image without corners terminates (the reference would not) and returns nothing
     got, fgot = api.get_sorted_keypoints(ctx, np.full((40, 40), 9, np.uint8), 10, 10.0)
     assert len(got) == 0
+
+
+# ---- committed golden vectors (tests/golden/make_golden.py) -------------------------------------
+def test_golden_vectors_on_gpu(ctx):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as MG
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_r01.npz"))
+    for name in MG.CONFIGS:
+        c = MG.track_case(name)
+        pyr = api.ImagePyramid(ctx, c["frame"], c["subs"])
+        try:
+            assert [MG.crc(pyr.image(l)) for l in range(len(c["subs"]))] == gold[name + "/pyr_crc"].tolist()
+            res = api.track_batch(ctx, pyr, c["jobs"])
+        finally:
+            pyr.close()
+        assert np.array_equal(np.array([(r["x"], r["y"], r["levels_run"]) for r in res], np.int32), gold[name + "/track_xy_levels"])
+        got = np.array([(r["response"], r["dx"], r["dy"]) for r in res], np.float32)
+        assert np.array_equal(got.view(np.uint32), gold[name + "/track_resp_dx_dy"].view(np.uint32))
+    mc = MG.match_cases()
+    res = [api.match_feature_in_area(ctx, c["im"], c["patch"], c["patch_mask"], c["area"], c["area_mask"], c["stride"], c["exact"], want_score=True)
+           for c in mc]
+    assert np.array_equal(np.array([(r["x"], r["y"]) for r in res], np.int32), gold["match/xy"])
+    got = np.array([(r["response"], r["dx"], r["dy"]) for r in res], np.float32)
+    assert np.array_equal(got.view(np.uint32), gold["match/resp_dx_dy"].view(np.uint32))
+    assert [MG.crc(r["score"]) for r in res] == gold["match/score_crc"].tolist()
+    for i, f in enumerate(MG.fast_frames()):
+        for thr in (10, 40):
+            kp, counts, rc = api.fast(ctx, f, thr, True)
+            assert rc == 0 and np.array_equal(kp[0], gold["fast/%d/t%d" % (i, thr)])
+        kps, fthr = api.get_sorted_keypoints(ctx, f, 100, 10.0)
+        assert [len(kps), fthr] == gold["gsk/%d/n_thr" % i].tolist()
+        assert np.array_equal(kps[:300], gold["gsk/%d/kps" % i])
+
+
+# ---- full BASELINE sizes: size-independent properties --------------------------------------------
+def test_c2_full_batch_properties(ctx, oracle):
+    """C2 at batch size (256 frames x 64 features): the batch is deterministic, a (near-)perfect
+    score only occurs where the template was cut, sampled jobs equal the oracle, and on a single
+    full-resolution level every template is found exactly where it was cut (SI = SP = CC)."""
+    w, h, subs, nfr, nfeat, ts = 640, 480, [1.0, 2.0, 4.0], 256, 64, 21
+    rng = np.random.default_rng(42)
+    base = [synth.canvas(-8, -8, w + 16, h + 16, 900 + s) for s in range(8)]
+    frames = np.empty((nfr, h, w), np.uint8)
+    jobs = []
+    for f in range(nfr):
+        u, v = int(rng.integers(-6, 7)), int(rng.integers(-6, 7))
+        frames[f] = base[f % 8][8 + v:8 + v + h, 8 + u:8 + u + w]
+        for (cx, cy) in synth.feature_grid(w, h, nfeat, ts + 30, rng):
+            proj = synth.cut_template(frames[f], cx, cy, ts, ts)
+            jobs.append(dict(frame=f, proj=proj, proj_mask=np.ones_like(proj), px=float(cx), py=float(cy),
+                             threshold=0.5, stride=3, truth=(cx, cy)))
+    pyr = api.ImagePyramid(ctx, frames, subs)
+    try:
+        a = api.track_batch(ctx, pyr, jobs)
+        b = api.track_batch(ctx, pyr, jobs)
+        assert a == b                                              # idempotent / deterministic
+        # wherever the walk reports a (near-)perfect score, it is at the place the template was cut
+        perfect = [(r, j) for r, j in zip(a, jobs) if r["response"] > 0.9999]
+        assert len(perfect) > 1000 and all((r["x"], r["y"]) == j["truth"] for r, j in perfect)
+        assert all(abs(r["dx"]) <= 0.5 and abs(r["dy"]) <= 0.5 for r in a)
+        for i in rng.integers(0, len(jobs), 40):                   # sampled jobs against the oracle
+            j = jobs[int(i)]
+            levels = oracle.pyramid(frames[j["frame"]], subs)
+            r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+            g = a[int(i)]
+            assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"]) and _same_float(g["response"], r["response"])
+    finally:
+        pyr.close()
+    # single full-resolution level (41x41 window, stride 1): every template is found exactly where it was cut
+    pyr = api.ImagePyramid(ctx, frames, [1.0])
+    try:
+        one = api.track_batch(ctx, pyr, jobs)
+        assert all((r["x"], r["y"]) == j["truth"] and r["response"] > 0.9999 and r["levels_run"] == 1 for r, j in zip(one, jobs))
+    finally:
+        pyr.close()
+
+
+def test_c4_full_batch_fast_properties(ctx, oracle):
+    """C4: 64 frames of 1920x1080, FAST + NMS: no two keypoints are 8-adjacent, every
+    score is >= the threshold, lists are in row-major order, and sampled frames equal the oracle."""
+    w, h, n = 1920, 1080, 64
+    base = synth.canvas(0, 0, w + 64, h + 64, 4242)
+    frames = np.stack([base[(i * 7) % 64:(i * 7) % 64 + h, (i * 13) % 64:(i * 13) % 64 + w] for i in range(n)])
+    thr = 40          # at threshold 10 this very corner-rich texture exceeds the 65536-per-frame cap
+    kps, counts, rc = api.fast(ctx, frames, thr, True, cap=65536)
+    assert rc == 0 and (counts > 1000).all() and (counts <= 65536).all()
+    for i in range(n):
+        k = kps[i]
+        assert (k[:, 2] >= thr).all() and (k[:, 0] >= 3).all() and (k[:, 0] < w - 3).all() and (k[:, 1] >= 3).all() and (k[:, 1] < h - 3).all()
+        lin = k[:, 1].astype(np.int64) * w + k[:, 0].astype(np.int64)
+        assert (np.diff(lin) > 0).all()                             # row-major, no duplicates
+        occ = np.zeros((h + 2, w + 2), bool)
+        ys, xs = k[:, 1].astype(int) + 1, k[:, 0].astype(int) + 1
+        occ[ys, xs] = True
+        neigh = sum(occ[ys + dy, xs + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1)) - 1
+        assert (neigh == 0).all()
+    for i in (0, 37):
+        assert np.array_equal(kps[i], oracle.fast(frames[i], thr, True))

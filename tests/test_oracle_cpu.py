@@ -1,0 +1,156 @@
+"""CPU tests of the oracle (the checker): hand-checkable known answers, the reference's own
+property tests (tests/test_matching.cpp) and the committed golden vectors.  No GPU involved."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as MG  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden", "golden_r01.npz")
+
+
+def test_reference_property_tests_pass_on_the_oracle(oracle):
+    """tests/tests.cpp:11-17 runs the four tests back to back in ONE process: the glibc rand()
+    stream is never reseeded between them, so they are replayed here as one stream."""
+    first = True
+    for use_am, use_pm in [(0, 0), (1, 0), (0, 1), (1, 1)]:    # test_matching, ..Area, ..Patch, ..PatchArea
+        pt = oracle.PropTest(use_am, use_pm, seed=1) if first else _Continue(oracle, use_am, use_pm)
+        first = False
+        for _ in range(100):
+            c = pt.next()
+            r = oracle.match(c["im"], c["patch"], c["patch_mask"], c["area"], c["area_mask"], 1)
+            assert oracle.PropTest.accept(c, r["x"], r["y"], r["response"]), (use_am, use_pm, c["xpatch"], c["ypatch"], r)
+
+
+class _Continue:
+    """PropTest that keeps drawing from the current rand() state instead of reseeding."""
+
+    def __init__(self, oracle, uam, upm):
+        self._p = oracle.PropTest.__new__(oracle.PropTest)
+        self._p.uam, self._p.upm = int(uam), int(upm)
+
+    def next(self):
+        return self._p.next()
+
+
+def test_proptest_image_formula(oracle):
+    from slam_amd import synth
+    pt = oracle.PropTest(0, 0)
+    c = pt.next()
+    assert np.array_equal(c["im"], synth.proptest_image(c["w"], c["h"]))
+
+
+def test_resize_known_answers(oracle):
+    # exact 2x: (a+b+c+d+2)>>2 ; exact 3x: point sample at (3d+1, 3d+1)
+    ramp4 = (np.arange(16, dtype=np.uint8) * 10).reshape(4, 4)
+    r = oracle.resize(ramp4, 2, 2)
+    exp = np.array([[(0 + 10 + 40 + 50 + 2) >> 2, (20 + 30 + 60 + 70 + 2) >> 2],
+                    [(80 + 90 + 120 + 130 + 2) >> 2, (100 + 110 + 140 + 150 + 2) >> 2]], np.uint8)
+    assert np.array_equal(r, exp)
+    ramp6 = (np.arange(36, dtype=np.uint8) * 5).reshape(6, 6)
+    assert np.array_equal(oracle.resize(ramp6, 2, 2), ramp6[1::3, 1::3])
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    q = oracle.resize(im, 16, 12)                      # exact 4x: taps 4d+1, 4d+2 with equal weights
+    a = im.astype(np.int32)
+    exp4 = (a[1::4, 1::4] + a[1::4, 2::4] + a[2::4, 1::4] + a[2::4, 2::4] + 2) >> 2
+    assert np.array_equal(q, exp4.astype(np.uint8))
+    assert oracle.pyramid_level_size(640, 480, 3.0) == (213, 160)
+    assert oracle.pyramid_level_size(1280, 720, 8.0) == (160, 90)
+    same = oracle.pyramid(im, [1.0, 2.0])
+    assert np.array_equal(same[0], im) and same[1].shape == (24, 32)
+
+
+def test_match_known_answers(oracle):
+    rng = np.random.default_rng(1)
+    im = rng.integers(1, 256, (40, 50), dtype=np.uint8)
+    patch = im[10:21, 15:26].copy()                    # 11x11 centred on (20, 15)
+    r = oracle.match(im, patch, None, (0, 0, 50, 40), None, 1, want_score=True)
+    assert (r["x"], r["y"]) == (20, 15) and r["response"] == 1.0
+    # a patch against itself with a mask: f32 formula gives exactly 1 as well
+    r = oracle.match(im, patch, np.ones_like(patch), (10, 5, 21, 21), None, 1)
+    assert (r["x"], r["y"], r["response"]) == (20, 15, 1.0)
+    # all-zero image: masked cells are 0/0 = NaN and never win -> minMaxLoc finds nothing
+    z = np.zeros((20, 20), np.uint8)
+    r = oracle.match(z, patch, np.ones_like(patch), (2, 2, 12, 12), None, 1, want_score=True)
+    assert np.isnan(r["score"]).all() and (r["x"], r["y"], r["response"]) == (1, 1, 0.0)
+    # unmasked on zeros: matchTemplate's t = 0 -> 0, borders NaN
+    r = oracle.match(z, patch, None, (2, 2, 12, 12), None, 1, want_score=True)
+    assert r["response"] == 0.0
+    # window off the image (matching.cpp:26-30)
+    r = oracle.match(im, patch, None, (60, 5, 10, 10), None, 1)
+    assert (r["x"], r["y"], r["response"]) == (0, 0, -1.0)
+    # stride lattice: masked interior cells off the lattice keep -1
+    r = oracle.match(im, patch, np.ones_like(patch), (10, 10, 12, 12), None, 3, want_score=True)
+    s = r["score"]
+    assert (s[::3, ::3] > -1).all() and (np.delete(np.delete(s, np.s_[::3], 0), np.s_[::3], 1) == -1).all()
+    # unmasked interior ignores the stride (matching.cpp:151-153)
+    r = oracle.match(im, patch, None, (10, 10, 12, 12), None, 3, want_score=True)
+    assert (r["score"] > -1).all()
+
+
+def test_fast_known_answers(oracle):
+    # one bright pixel on a dark 7x7 image is no corner (the ring is uniformly darker: 16 contiguous
+    # -> a corner with all ring pixels darker by 200): v - ring = 200 on the whole ring
+    im = np.full((7, 7), 10, np.uint8)
+    im[3, 3] = 210
+    kp = oracle.fast(im, 20, True)
+    assert kp.tolist() == [[3.0, 3.0, 199.0]]          # score = min over arc of (v - ring) - 1
+    assert len(oracle.fast(im, 200, True)) == 0        # |diff| must exceed the threshold strictly
+    # a step corner: bright quadrant
+    im = np.full((15, 15), 50, np.uint8)
+    im[:8, :8] = 150
+    kp = oracle.fast(im, 30, False)                    # (equal scores on the plateau: NMS would drop them all)
+    assert [7.0, 7.0, 99.0] in kp.tolist()             # 11 contiguous darker ring pixels, all by 100
+    sm = oracle.fast_score_map(im)
+    for x, y, s in kp.tolist():
+        assert sm[int(y), int(x)] == int(s)            # threshold-free score equals the stored score
+    # NMS never keeps two 8-adjacent corners
+    from slam_amd import synth
+    f = synth.frame(160, 120, 3)
+    kp = oracle.fast(f, 10, True)
+    pts = {(int(x), int(y)) for x, y, _ in kp.tolist()}
+    assert not any((x + dx, y + dy) in pts for (x, y) in pts for dx in (-1, 0, 1) for dy in (-1, 0, 1) if (dx, dy) != (0, 0))
+    # corner at threshold t  <=>  threshold-free score >= t
+    sm = oracle.fast_score_map(f)
+    nn = oracle.fast(f, 25, False)
+    assert {(int(x), int(y)) for x, y, _ in nn.tolist()} == {(x, y) for y, x in zip(*np.nonzero(sm >= 25)) if 3 <= x < 157 and 3 <= y < 117}
+
+
+def test_get_sorted_keypoints_contract(oracle):
+    from slam_amd import synth
+    f = synth.frame(320, 240, 9)
+    kps, thr = oracle.get_sorted_keypoints(f, 100, 10.0)
+    assert len(kps) >= 100
+    r = kps[:, 2]
+    assert (np.diff(r) <= 0).all()                     # sorted by response, descending
+    if len(kps) > 200:
+        assert thr == kps[int(100 * 1.9), 2]           # new_point.cpp:125-126
+    none, thr2 = oracle.get_sorted_keypoints(np.full((30, 30), 7, np.uint8), 10, 10.0)
+    assert len(none) == 0                              # terminates on a cornerless image
+
+
+def test_golden_vectors_are_reproduced_by_the_oracle(oracle):
+    assert os.path.exists(GOLD), "run tests/golden/make_golden.py"
+    gold = np.load(GOLD)
+    for name in MG.CONFIGS:
+        c = MG.track_case(name)
+        levels = oracle.pyramid(c["frame"], c["subs"])
+        assert [MG.crc(l) for l in levels] == gold[name + "/pyr_crc"].tolist()
+        res = [oracle.track(levels, c["subs"], j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+               for j in c["jobs"]]
+        assert np.array_equal(np.array([(r["x"], r["y"], r["levels_run"]) for r in res], np.int32), gold[name + "/track_xy_levels"])
+        got = np.array([(r["response"], r["dx"], r["dy"]) for r in res], np.float32)
+        assert np.array_equal(got.view(np.uint32), gold[name + "/track_resp_dx_dy"].view(np.uint32))
+    mc = MG.match_cases()
+    res = [oracle.match(c["im"], c["patch"], c["patch_mask"], c["area"], c["area_mask"], c["stride"], c["exact"], want_score=True) for c in mc]
+    assert np.array_equal(np.array([(r["x"], r["y"]) for r in res], np.int32), gold["match/xy"])
+    assert [MG.crc(r["score"]) for r in res] == gold["match/score_crc"].tolist()
+    for i, f in enumerate(MG.fast_frames()):
+        for thr in (10, 40):
+            assert np.array_equal(oracle.fast(f, thr, True), gold["fast/%d/t%d" % (i, thr)])
+    assert np.array_equal(gold["kat/resize_6x6_by3"], (np.arange(36, dtype=np.uint8) * 5).reshape(6, 6)[1::3, 1::3])
