@@ -31,7 +31,11 @@ STRIDE = 3
 THRESHOLD = 0.98
 SEQ_LEN = 32
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-DOT4_PEAK_MACS = 256 * 4 * 32 * 4 * 2.4e9   # CUs x SIMDs x lanes x MAC/lane/clk x Hz (packed u8 dot)
+# Packed u8 dot (v_dot4_u32_u8): measured on gfx950 at ~4.5 cycles per wave64 instruction per SIMD
+# (profiles/tools/valu_rate.hip), i.e. half the rate of a plain 32-bit VALU op:
+# CUs x SIMDs x 64 lanes x 4 MAC / 4.5 clk x 2.4 GHz.
+DOT4_PEAK_MACS = 256 * 4 * 64 * 4 / 4.5 * 2.4e9
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_track_traffic.json")
 
 TRACK_JOB_DT = np.dtype([("frame", "<i4"), ("projw", "<i4"), ("projh", "<i4"), ("_pad", "<i4"),
                          ("proj_off", "<i8"), ("mask_off", "<i8"), ("px", "<f4"), ("py", "<f4"),
@@ -142,7 +146,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from slam_amd import api, capi
+    from slam_amd import api, capi, parallel
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -228,15 +232,15 @@ def main():
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     tot_pos = float(positions)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        p = torch.tensor([tot_pos], dtype=torch.float64, device=dev)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        tot_pos = float(p.item())
+    elapsed, tot_pos = parallel.reduce_max_sum(elapsed, tot_pos, dev)
 
     if rank == 0:
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+        if os.path.exists(TRAFFIC_FILE):
+            with open(TRAFFIC_FILE) as fh:
+                tf = json.load(fh)
+            if tf.get("frames_per_gpu") == nframes:
+                traffic = tf["track_kernel"]["hbm_bytes_per_launch"]
         ach = alg_bytes / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "NCC patch-match positions/sec (pyramid build + coarse-to-fine template search)",
@@ -253,7 +257,7 @@ def main():
                        "frames_per_s": nframes * world * args.steps / elapsed, "tracked_fraction": tracked,
                        "parallelism": "frames sharded over %d GPU(s), no collective on the data path" % world},
             "roofline": {"bound": "hbm", "kernel": "track_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                          "u8_mac_per_s": macs / (kern_ms * 1e-3), "frac_of_packed_dot_peak": macs / (kern_ms * 1e-3) / DOT4_PEAK_MACS},
             "cpu_baseline": cpu,

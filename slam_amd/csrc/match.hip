@@ -23,7 +23,9 @@ static_assert(SLAM_WG == 64, "the search kernels assume one wavefront per workgr
 // template pixels.  Cold path: templates too wide for the tiled core (or for the LDS it was given)
 // and the in-GPU cross-check of the tiled core (SLAM_HIP_FORCE_DIRECT=1).  Not inlined, so that it
 // does not weigh on the register allocation and code size of the tiled path.
-__device__ __noinline__ void direct_cells(Geo g, Tmpl t, float* scores, unsigned long long* spfull_out, Best* best_out) {
+struct DirectOut { unsigned long long spfull; float v; int idx; };   // returned in registers
+
+__device__ __noinline__ DirectOut direct_cells(Geo g, Tmpl t, float* scores) {
     const int lane = threadIdx.x;
     unsigned long long spfull;
     {   // |patch0|^2 over the whole template (matching.cpp:63,109; template norm of matchTemplate)
@@ -57,8 +59,9 @@ __device__ __noinline__ void direct_cells(Geo g, Tmpl t, float* scores, unsigned
         if (scores) scores[c] = sc;
         best_update(b, sc, c);
     }
-    *spfull_out = spfull;
-    *best_out = best_wave(b);
+    b = best_wave(b);
+    DirectOut o = {spfull, b.v, b.idx};
+    return o;
 }
 
 // Score-map value of cell (nx, ny) recomputed by the 64 lanes together (-1 for unvisited cells).
@@ -91,7 +94,10 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
     fs.valid = false;
     const bool use_fast = !force_direct && fast_supported(g, lp);
     if (use_fast) fast_search(g, t, scores, lds, lp, refine_always, refine_below, spfull, nm, b, fs STAMP_PASS);
-    else direct_cells(g, t, scores, &spfull, &b);
+    else {
+        const DirectOut d = direct_cells(g, t, scores);
+        spfull = d.spfull; b.v = d.v; b.idx = d.idx;
+    }
     STAMP(20);
     CoreOut o;
     o.dx = 0.f; o.dy = 0.f;

@@ -1,64 +1,203 @@
 // Batched image pyramid: every level is a bilinear resize of the FULL-resolution frame
 // (imagePyramid.hpp:27), levels with sub == 1 alias the input (imagePyramid.hpp:24-25).
+#include <algorithm>
 #include <cmath>
 
 #include "slam_internal.h"
 
 namespace {
 
-// One thread produces 4 horizontally adjacent output pixels of one frame and stores them as one
-// dword.  Tap tables (source offset + two 11-bit weights per output index) are read-only and
-// shared by all frames.  Arithmetic is cv::resize's 8-bit INTER_LINEAR path:
+// One launch builds every resized level of every frame.  A workgroup owns one tile of one level of
+// one frame: `rb` output rows x `xt` output columns.  It stages the 2*rb source rows the tile needs
+// (clamped row indices, dword-coalesced, only the column span under the tile) and the tile's tap
+// tables into LDS, then each thread produces 4 horizontally adjacent output pixels per item and
+// stores them as one dword.  Arithmetic is cv::resize's 8-bit INTER_LINEAR path:
 //   H(r)  = S[r][sx]*a0 + S[r][sx+1]*a1                    (int32)
 //   out   = (((b0*(H(r0)>>4))>>16) + ((b1*(H(r1)>>4))>>16) + 2) >> 2
-__global__ __launch_bounds__(256) void pyr_resize_kernel(
-    const uint8_t* __restrict__ src, int sw, int sh, long long spitch, long long sstride,
-    uint8_t* __restrict__ dst, int dw, int dh, long long dpitch, long long dstride,
-    const int32_t* __restrict__ xofs, const uint32_t* __restrict__ xcoef,
-    const int32_t* __restrict__ yofs, const uint32_t* __restrict__ ycoef) {
-    const int gx = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;   // first of 4 output columns
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int frame = blockIdx.z;
-    if (gx >= dw || dy >= dh) return;
-    const uint8_t* S = src + (long long)frame * sstride;
-    const int sy = yofs[dy];
-    const uint32_t yc = ycoef[dy];
-    const int b0 = (int)(int16_t)(yc & 0xffff), b1 = (int)(int16_t)(yc >> 16);
-    const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
-    const uint8_t* S0 = S + (long long)r0 * spitch;
-    const uint8_t* S1 = S + (long long)r1 * spitch;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int dx = min(gx + i, dw - 1);
-        const int sx = xofs[dx];
-        const uint32_t xc = xcoef[dx];
-        const int a0 = (int)(int16_t)(xc & 0xffff), a1 = (int)(int16_t)(xc >> 16);
-        const int sx1 = min(sx + 1, sw - 1);
-        const int h0 = (int)S0[sx] * a0 + (int)S0[sx1] * a1;
-        const int h1 = (int)S1[sx] * a0 + (int)S1[sx1] * a1;
-        const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)(v & 0xff) << (8 * i);
+// Workgroup ids interleave 8 frames (id % 8 picks the frame within a group of 8): with the usual
+// round-robin placement of workgroups over the 8 XCDs, all tiles of all levels of a frame then run
+// on one XCD and the second level's reads of the frame hit that XCD's L2.
+struct PyrLevelArgs {
+    uint8_t* dst;
+    long long dpitch, dstride;
+    const int32_t* xofs; const uint32_t* xcoef;
+    const int32_t* yofs; const uint32_t* ycoef;
+    int dw, dh;
+    int xt, ncolt;      // output columns per tile (multiple of 4), tiles per row
+    int rb, nband;      // output rows per tile, tiles per column
+    int span;           // bytes of one staged source row in LDS (multiple of 4)
+    int unit0;          // first work unit of this level within a frame
+};
+
+struct PyrArgs {
+    const uint8_t* src;
+    long long spitch, sstride;
+    int sw, sh, nframes, nlev, units;
+    PyrLevelArgs lev[SLAM_HIP_MAX_LEVELS];
+};
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void pyr_build_kernel(PyrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pyr_lds[];
+    const unsigned per = 8u * (unsigned)a.units;
+    const unsigned fg = blockIdx.x / per, rem = blockIdx.x - fg * per;
+    const int unit = (int)(rem >> 3);
+    const int frame = (int)(fg * 8u + (rem & 7u));
+    if (frame >= a.nframes) return;
+    int l = 0;
+    for (int k = 1; k < a.nlev; k++)
+        if (unit >= a.lev[k].unit0) l = k;
+    const PyrLevelArgs& L = a.lev[l];
+    const int local = unit - L.unit0;
+    const int band = local / L.ncolt, colt = local - band * L.ncolt;
+    const int xb = colt * L.xt, xn = min(L.xt, L.dw - xb);
+    const int yb = band * L.rb, yn = min(L.rb, L.dh - yb);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int span = L.span;
+    const int cx0 = L.xofs[xb] & ~3;                                   // first staged source column
+    const int ndw = min(span, ((a.sw + 3) & ~3) - cx0) >> 2;           // dwords staged per row
+
+    unsigned char* rows = pyr_lds;
+    uint2* xtab = reinterpret_cast<uint2*>(pyr_lds + ((2 * L.rb * span + 7) & ~7));
+    uint32_t* ytab = reinterpret_cast<uint32_t*>(xtab + ((L.xt + 3) & ~3));
+
+    const int xpad = (xn + 3) & ~3;
+    for (int i = tid; i < xpad; i += 256) {
+        const int dx = min(xb + i, L.dw - 1);
+        const int sx = L.xofs[dx];
+        const unsigned o = (unsigned)(sx - cx0), o1 = (unsigned)(min(sx + 1, a.sw - 1) - cx0);
+        xtab[i] = make_uint2(o | (o1 << 16), L.xcoef[dx]);
     }
-    // rows are padded to a multiple of 4 bytes, so the last dword of a row may be stored whole
-    uint8_t* D = dst + (long long)frame * dstride + (long long)dy * dpitch + gx;
-    *reinterpret_cast<uint32_t*>(D) = packed;
+    if (tid < yn) ytab[tid] = L.ycoef[yb + tid];
+
+    const uint8_t* S = a.src + (long long)frame * a.sstride;
+    for (int k = wave; k < 2 * yn; k += 4) {
+        const int r = min(max(L.yofs[yb + (k >> 1)] + (k & 1), 0), a.sh - 1);
+        const uint8_t* R = S + (long long)r * a.spitch + cx0;
+        uint32_t* dstrow = reinterpret_cast<uint32_t*>(rows + k * span);
+        for (int c = lane; c < ndw; c += 64) {
+            uint32_t v;
+            if (ALIGNED) {
+                v = *reinterpret_cast<const uint32_t*>(R + 4 * c);
+            } else {                                                   // any pitch / base: byte loads, clamped
+                const int lim = a.sw - 1 - cx0;
+                v = (uint32_t)R[min(4 * c, lim)] | ((uint32_t)R[min(4 * c + 1, lim)] << 8) |
+                    ((uint32_t)R[min(4 * c + 2, lim)] << 16) | ((uint32_t)R[min(4 * c + 3, lim)] << 24);
+            }
+            dstrow[c] = v;
+        }
+    }
+    __syncthreads();
+
+    const int ncg = xpad >> 2;
+    const int items = yn * ncg;
+    const float rncg = 1.0f / (float)ncg;
+    uint8_t* D = L.dst + (long long)frame * L.dstride + (long long)yb * L.dpitch + xb;
+    for (int item = tid; item < items; item += 256) {
+        const int row = (int)(((float)item + 0.5f) * rncg);           // items <= 2048: exact
+        const int cg = item - row * ncg;
+        const uint32_t yc = ytab[row];
+        const int b0 = (int)(int16_t)(yc & 0xffff), b1 = (int)(int16_t)(yc >> 16);
+        const unsigned char* R0 = rows + (2 * row) * span;
+        const unsigned char* R1 = R0 + span;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint2 e = xtab[cg * 4 + i];
+            const unsigned o = e.x & 0xffffu, o1 = e.x >> 16;
+            const int a0 = (int)(int16_t)(e.y & 0xffff), a1 = (int)(int16_t)(e.y >> 16);
+            const int h0 = (int)R0[o] * a0 + (int)R0[o1] * a1;
+            const int h1 = (int)R1[o] * a0 + (int)R1[o1] * a1;
+            const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 0xff) << (8 * i);
+        }
+        // rows are padded to a multiple of 4 bytes, so the last dword of a row may be stored whole
+        *reinterpret_cast<uint32_t*>(D + (long long)row * L.dpitch + cg * 4) = packed;
+    }
+}
+
+const int PYR_LDS_BUDGET = 40 * 1024;
+
+int pyr_lds_bytes(int rb, int xt, int span) {
+    return ((2 * rb * span + 7) & ~7) + ((xt + 3) & ~3) * 8 + rb * 4;
+}
+
+// Largest staged row span (bytes, multiple of 4) over the column tiles of width xt.
+int pyr_span(const std::vector<int32_t>& xofs, int sw, int dw, int xt) {
+    int span = 4;
+    for (int xb = 0; xb < dw; xb += xt) {
+        const int xe = std::min(dw, xb + xt);
+        const int cx0 = xofs[xb] & ~3;
+        const int last = std::min(sw - 1, xofs[xe - 1] + 1);
+        span = std::max(span, ((last + 4) & ~3) - cx0);
+    }
+    return span;
+}
+
+}  // namespace
+
+// Tile shape of one resized level: as many output rows / columns per workgroup as fit the LDS budget.
+int slam_pyr_plan_level(const std::vector<int32_t>& xofs, int sw, int dw, int dh, slam_pyr_plan* out) {
+    int xt = (std::min(dw, 1024) + 3) & ~3, rb = 8;
+    int span = pyr_span(xofs, sw, dw, xt);
+    while (pyr_lds_bytes(rb, xt, span) > PYR_LDS_BUDGET || span > 65532) {
+        if (rb > 1 && span <= 65532) rb >>= 1;
+        else if (xt > 4) { xt = ((xt >> 1) + 3) & ~3; span = pyr_span(xofs, sw, dw, xt); }
+        else return SLAM_HIP_EINVAL;
+    }
+    out->xt = xt; out->ncolt = (dw + xt - 1) / xt;
+    out->rb = rb; out->nband = (dh + rb - 1) / rb;
+    out->span = span; out->lds = pyr_lds_bytes(rb, xt, span);
+    return SLAM_HIP_OK;
+}
+
+namespace {
+
+struct PyrLevelHost {
+    uint8_t* dst; size_t dpitch, dstride; int dw, dh;
+    const int32_t* xofs; const uint32_t* xcoef; const int32_t* yofs; const uint32_t* ycoef;
+    slam_pyr_plan plan;
+};
+
+int pyr_launch(slam_ctx* ctx, const uint8_t* src, int sw, int sh, size_t spitch, size_t sstride, int nframes,
+               const PyrLevelHost* lev, int nlev) {
+    if (nlev == 0) return SLAM_HIP_OK;
+    PyrArgs a{};
+    a.src = src; a.spitch = (long long)spitch; a.sstride = (long long)sstride;
+    a.sw = sw; a.sh = sh; a.nframes = nframes; a.nlev = nlev;
+    int units = 0, lds = 0;
+    for (int l = 0; l < nlev; l++) {
+        PyrLevelArgs& L = a.lev[l];
+        L.dst = lev[l].dst; L.dpitch = (long long)lev[l].dpitch; L.dstride = (long long)lev[l].dstride;
+        L.xofs = lev[l].xofs; L.xcoef = lev[l].xcoef; L.yofs = lev[l].yofs; L.ycoef = lev[l].ycoef;
+        L.dw = lev[l].dw; L.dh = lev[l].dh;
+        L.xt = lev[l].plan.xt; L.ncolt = lev[l].plan.ncolt; L.rb = lev[l].plan.rb; L.nband = lev[l].plan.nband;
+        L.span = lev[l].plan.span; L.unit0 = units;
+        units += L.ncolt * L.nband;
+        lds = std::max(lds, lev[l].plan.lds);
+    }
+    a.units = units;
+    const long long groups = ((long long)nframes + 7) / 8;
+    const long long grid = groups * 8 * units;
+    if (grid > 0x7fffffffLL) return slam_set_error(ctx, SLAM_HIP_EINVAL, "pyramid: batch too large for one launch (%lld workgroups)", grid);
+    const bool aligned = (((uintptr_t)src | spitch | sstride) & 3) == 0;
+    if (aligned) hipLaunchKernelGGL(pyr_build_kernel<true>, dim3((unsigned)grid), dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(pyr_build_kernel<false>, dim3((unsigned)grid), dim3(256), lds, ctx->stream, a);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    return SLAM_HIP_OK;
 }
 
 }  // namespace
 
 int slam_launch_pyramid(slam_ctx* ctx, slam_pyr* pyr) {
+    PyrLevelHost lev[SLAM_HIP_MAX_LEVELS];
+    int n = 0;
     for (int l = 0; l < pyr->nlev; l++) {
         if (!pyr->d_level[l]) continue;   // aliased level
-        dim3 grid((pyr->lw[l] + 255) / 256, (pyr->lh[l] + 3) / 4, pyr->nframes);
-        hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, ctx->stream,
-                           pyr->d_frames, pyr->w, pyr->h, (long long)pyr->pitch0, (long long)pyr->stride0,
-                           pyr->d_level[l], pyr->lw[l], pyr->lh[l], (long long)pyr->lpitch[l],
-                           (long long)pyr->lstride[l], pyr->d_xofs[l], pyr->d_xcoef[l],
-                           pyr->d_yofs[l], pyr->d_ycoef[l]);
-        SLAM_HIP_CHECK(ctx, hipGetLastError());
+        lev[n++] = PyrLevelHost{pyr->d_level[l], pyr->lpitch[l], pyr->lstride[l], pyr->lw[l], pyr->lh[l],
+                                pyr->d_xofs[l], pyr->d_xcoef[l], pyr->d_yofs[l], pyr->d_ycoef[l], pyr->plan[l]};
     }
-    return SLAM_HIP_OK;
+    return pyr_launch(ctx, pyr->d_frames, pyr->w, pyr->h, pyr->pitch0, pyr->stride0, pyr->nframes, lev, n);
 }
 
 static void pyr_refresh_dev(slam_pyr* p) {
@@ -106,6 +245,9 @@ extern "C" int slam_hip_pyramid_create(slam_ctx* ctx, int w, int h, int nlev, co
         std::vector<uint32_t> xc, yc;
         slam_resize_tables(w, dw, xo, xc, true);
         slam_resize_tables(h, dh, yo, yc, false);
+        if (slam_pyr_plan_level(xo, w, dw, dh, &p->plan[l]) != SLAM_HIP_OK) {
+            rc = slam_set_error(ctx, SLAM_HIP_EINVAL, "pyramid_create: level %d cannot be tiled", l); break;
+        }
         void* ptr = nullptr;
         auto alloc_copy = [&](const void* src, size_t bytes, void** dptr) -> int {
             hipError_t e = hipMalloc(dptr, bytes);
@@ -243,11 +385,11 @@ extern "C" int slam_hip_debug_resize(slam_ctx* ctx, const uint8_t* src, int sw, 
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(d_yo, yo.data(), dh * 4, hipMemcpyHostToDevice, ctx->stream));
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(d_yc, yc.data(), dh * 4, hipMemcpyHostToDevice, ctx->stream));
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors go out of scope below
-    dim3 grid((dw + 255) / 256, (dh + 3) / 4, 1);
-    hipLaunchKernelGGL(pyr_resize_kernel, grid, dim3(256), 0, ctx->stream,
-                       base + off_src, sw, sh, (long long)sw, 0LL, base + off_dst, dw, dh, (long long)dp, 0LL,
-                       d_xo, d_xc, d_yo, d_yc);
-    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    PyrLevelHost lev{base + off_dst, dp, 0, dw, dh, d_xo, d_xc, d_yo, d_yc, {}};
+    if (slam_pyr_plan_level(xo, sw, dw, dh, &lev.plan) != SLAM_HIP_OK)
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "debug_resize: cannot be tiled");
+    rc = pyr_launch(ctx, base + off_src, sw, sh, (size_t)sw, 0, 1, &lev, 1);
+    if (rc != SLAM_HIP_OK) return rc;
     SLAM_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, base + off_dst, dp, dw, dh, hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SLAM_HIP_OK;

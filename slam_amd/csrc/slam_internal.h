@@ -38,6 +38,11 @@ struct slam_pyr_dev {
     slam_level_dev lev[SLAM_HIP_MAX_LEVELS];
 };
 
+// Tile shape of the pyramid kernel for one resized level.
+struct slam_pyr_plan {
+    int xt = 0, ncolt = 0, rb = 0, nband = 0, span = 0, lds = 0;
+};
+
 struct slam_pyr {
     int device = 0;
     int w = 0, h = 0, nlev = 0, nframes = 0;
@@ -51,6 +56,7 @@ struct slam_pyr {
     uint32_t* d_xcoef[SLAM_HIP_MAX_LEVELS] = {nullptr};
     int32_t* d_yofs[SLAM_HIP_MAX_LEVELS] = {nullptr};
     uint32_t* d_ycoef[SLAM_HIP_MAX_LEVELS] = {nullptr};
+    slam_pyr_plan plan[SLAM_HIP_MAX_LEVELS];
     uint8_t* d_upload = nullptr;     // owned copy of host frames (slam_hip_pyramid_build)
     size_t upload_bytes = 0;
     const uint8_t* d_frames = nullptr;   // current level-0 source
@@ -77,6 +83,7 @@ void slam_resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::ve
 
 // kernels' host launchers (defined in the .hip files)
 int slam_launch_pyramid(slam_ctx* ctx, slam_pyr* pyr);
+int slam_pyr_plan_level(const std::vector<int32_t>& xofs, int sw, int dw, int dh, slam_pyr_plan* out);
 
 static_assert(sizeof(slam_match_job) == 72 && sizeof(slam_match_result) == 24, "ABI struct layout");
 static_assert(sizeof(slam_track_job) == 48 && sizeof(slam_track_result) == 28, "ABI struct layout");
