@@ -1,0 +1,88 @@
+// Host-side mirror of the reference's interfaces on the image hot path, implemented on top of the
+// C ABI in include/slam_hip.h (libslam_hip.so).  Names, argument order and sentinel behaviour follow
+// the reference so that its call sites compile against this header unchanged:
+//   SLAM::matchFeatureInArea       SLAM.hpp:92-98, matching.cpp:9-228
+//   ImagePyramid<byte>             imagePyramid.hpp:9-34
+//   SLAM::Feature::track           SLAM.hpp:62-65, feature.cpp:102-173   (the level walk; see below)
+//   SLAM::getSortedKeyPoints       SLAM.hpp:118-119, new_point.cpp:113-127
+//   SLAM::matchPoints              SLAM.hpp:106-107, matching.cpp:230-269 (batched over features)
+// Device errors (no GPU, failed allocation) are reported by std::runtime_error; the reference's own
+// sentinels (response -1 and (0,0) for an off-image window, (-1,-1) for an empty projection) are kept.
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "slam_cvtypes.hpp"
+#include "slam_hip.h"
+
+typedef unsigned char byte;
+typedef cv::Mat_<byte> matb;
+
+namespace slamhip {
+// The calling thread's context on device $SLAM_HIP_DEVICE (default 0), created on first use.
+slam_ctx* context();
+// Throws std::runtime_error carrying slam_hip_last_error_string when rc < 0.
+void check(int rc, const char* what);
+}  // namespace slamhip
+
+// imagePyramid.hpp:9-34.  `images` are host copies of the levels (what reference code indexes);
+// the levels also stay resident on the device for the search calls below.
+template <typename imtype> class ImagePyramid;
+
+template <> class ImagePyramid<byte> {
+public:
+    typedef cv::Mat_<byte> mati;
+    std::vector<mati> images;
+    std::vector<float> subsamples;
+    ImagePyramid(const mati& imFullSize, const std::vector<float>& subsamples);
+    ~ImagePyramid();
+    ImagePyramid(const ImagePyramid&) = delete;
+    ImagePyramid& operator=(const ImagePyramid&) = delete;
+    size_t nSubs() const { return subsamples.size(); }
+    const slam_pyr* device() const { return pyr_; }
+private:
+    slam_pyr* pyr_ = nullptr;
+};
+
+class SLAM {
+public:
+    // SLAM.hpp:82-86
+    struct Match {
+        cv::Point2f pos;
+        int iFeature;
+        Match(const cv::Point2f& pos_, int iFeature_) : pos(pos_), iFeature(iFeature_) {}
+    };
+
+    // What Feature::project (feature.cpp:53-100) hands to the search: the warped template, its
+    // {0,1} mask and the predicted image point.  The warp itself stays on the CPU in the caller.
+    struct Projection {
+        matb proj, projMask;
+        cv::Point2f p2d;
+    };
+
+    struct Feature {
+        // feature.cpp:117-172 for an already projected feature: coarse-to-fine walk over the
+        // pyramid levels on the device.  Returns Point2i(trackedPoint); (-1,-1) and response -1
+        // when the projection is empty (feature.cpp:112-115).
+        static cv::Point2i track(const ImagePyramid<byte>& pyramid, const Projection& p, float threshold,
+                                 int stride, float& response);
+    };
+
+    // SLAM.hpp:92-98
+    static cv::Point2i matchFeatureInArea(const cv::Mat_<byte>& im, const cv::Mat_<byte>& patch,
+                                          const cv::Mat_<byte>* patchMask, const cv::Rect& areaRect,
+                                          const matb* areaMask, int stride, float& response,
+                                          bool useExactAreaMask = false);
+
+    // matching.cpp:230-269 after the projections: every feature of one frame in one batched launch;
+    // keeps Match(pos, i) when response > threshold (matching.cpp:262-263).  stride 3 as matching.cpp:250.
+    static void matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Projection>& features,
+                            std::vector<Match>& matches, float threshold = .95f, int stride = 3,
+                            std::vector<float>* responses = nullptr);
+
+    // SLAM.hpp:118-119; fastThreshold is the mutable member of SLAM.hpp:22.
+    void getSortedKeyPoints(const matb& im, size_t nMinPts, std::vector<cv::KeyPoint>& out) const;
+    mutable float fastThreshold = 10.f;
+};
