@@ -1,13 +1,17 @@
 // FAST-9-16 corner score + non-max suppression (cv::FAST as called at new_point.cpp:120) and
 // SLAM::getSortedKeyPoints (new_point.cpp:113-127).
 //
-// Kernel 1 (fast_band_kernel): one workgroup per band of R image rows of one frame.  Phase A
-// writes the stored corner score (score for corners, 0 otherwise) of rows -1..R of the band into
-// an LDS tile; phase B applies the 3x3 strict non-max test and compacts the survivors IN ROW-MAJOR
-// ORDER (each wavefront owns R/4 consecutive rows and compacts with ballots) into an LDS key list;
-// the band's keys are then appended to the frame's key pool.
+// Kernel 1 (fast_band_kernel): one workgroup (4 wavefronts) per band of R image rows of one frame.
+//   Phase 1+2, per 256-pixel chunk of the band: the chunk's pixels (+ halo) are staged into LDS; each
+//   lane tests 4 adjacent pixels with the opposite-pair test (a 9-long arc contains one pixel of
+//   every opposite ring pair, so "all 8 pairs have a brighter / darker member" is necessary), the
+//   wavefront compacts the candidates and computes the exact score only for those, writing the
+//   stored score (score for corners, 0 otherwise) of band rows -1..R into an LDS score tile.
+//   Phase 3: each wavefront walks its rows of the score tile in row-major order, applies the strict
+//   3x3 non-max test to the non-zero entries and compacts survivors with ballots; a first pass
+//   counts, the band reserves a slice of the frame's key pool, a second pass writes the keys.
 // Kernel 2 (fast_gather_kernel): one workgroup per frame concatenates the bands in band order,
-// which gives cv::FAST's row-major keypoint order, and converts keys to keypoints.
+//   which gives cv::FAST's row-major keypoint order, and converts keys to keypoints.
 #include <algorithm>
 #include <cmath>
 
@@ -16,23 +20,31 @@
 namespace {
 
 constexpr int FAST_WG = 256;
-constexpr int FAST_LDS_BUDGET = 80 * 1024;
+constexpr int FAST_CHUNK = 256;                 // pixels per chunk: 4 per lane
+constexpr int FAST_PPITCH = FAST_CHUNK + 8;     // pixel tile pitch: 4 halo columns each side
+constexpr int FAST_LDS_BUDGET = 40 * 1024;
 
 struct FastPlan {
-    int R;            // rows per band (multiple of 4)
+    int R;            // rows per band; R + 2 score rows are a multiple of 4 (one share per wavefront)
     int nbands;
-    int keycap_wave;  // LDS key capacity of one wavefront
+    int spitch;       // score tile pitch (bytes): 4 + w + 4, rounded up to 4
     size_t lds_bytes;
 };
 
-bool fast_plan(int w, int h, int nonmax, FastPlan& p) {
-    // LDS: (R+2)*w score bytes + 4 wave lists of keycap_wave keys (4 bytes each)
-    for (int R = 32; R >= 4; R -= 4) {
-        const int rows_w = R / 4;
-        const int kc = nonmax ? ((w + 1) / 2) * ((rows_w + 1) / 2) : w * rows_w;
-        const size_t lds = (size_t)(R + 2) * w + (size_t)4 * kc * 4 + 64;
-        if (lds <= (size_t)FAST_LDS_BUDGET) {
-            p.R = R; p.nbands = (h + R - 1) / R; p.keycap_wave = kc; p.lds_bytes = (lds + 15) / 16 * 16;
+__host__ __device__ inline size_t fast_lds_bytes(int R, int spitch) {
+    // score tile + pixel chunk + candidate lists (4 wavefronts x up to 8 rows x 256 slots x 2 bytes);
+    // phase 3 reuses the pixel chunk + lists as one keep-flag byte per 4 pixels (R * spitch / 4 bytes)
+    const size_t work = (size_t)(R + 8) * FAST_PPITCH + 4 * 8 * 256 * 2;
+    const size_t flags = (size_t)R * (spitch / 4);
+    return (size_t)(R + 2) * spitch + (work > flags ? work : flags);
+}
+
+bool fast_plan(int w, int h, FastPlan& p) {
+    const int spitch = (w + 8 + 3) & ~3;
+    for (int R = 30; R >= 2; R -= 4) {
+        if (fast_lds_bytes(R, spitch) <= (size_t)FAST_LDS_BUDGET || R == 2) {
+            if (fast_lds_bytes(R, spitch) > 64 * 1024) return false;   // dynamic LDS of a plain launch
+            p.R = R; p.nbands = (h + R - 1) / R; p.spitch = spitch; p.lds_bytes = fast_lds_bytes(R, spitch);
             return true;
         }
     }
@@ -45,134 +57,258 @@ __host__ __device__ inline size_t fast_frame_words(int nbands, int cap) {
     return (size_t)4 + 2 * (size_t)((nbands + 3) / 4 * 4) + (size_t)((cap + 3) / 4 * 4);
 }
 
-__device__ __forceinline__ int ring_px(const uint8_t* p, long long pitch, int k) {
-    // (dx,dy) ring of cv::FAST, k = 0..15
-    constexpr int DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-    constexpr int DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-    return p[(long long)DY[k] * pitch + DX[k]];
+typedef __attribute__((address_space(3))) unsigned char fl_u8;
+typedef __attribute__((address_space(3))) unsigned short fl_u16;
+typedef __attribute__((address_space(3))) unsigned fl_u32;
+
+// byte i (0..11) of the 12-byte window {a, b, c}
+__device__ __forceinline__ int win_byte(unsigned a, unsigned b, unsigned c, int i) {
+    const unsigned wd = i < 4 ? a : (i < 8 ? b : c);
+    return (int)((wd >> (8 * (i & 3))) & 0xffu);
 }
 
-__device__ __forceinline__ unsigned rot16(unsigned m, int s) { return ((m >> s) | (m << (16 - s))) & 0xffffu; }
+// (dx, dy) of ring position k of cv::FAST's 16-pixel circle
+__device__ __forceinline__ constexpr int ring_dx(int k) {
+    constexpr int DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    return DX[k];
+}
+__device__ __forceinline__ constexpr int ring_dy(int k) {
+    constexpr int DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    return DY[k];
+}
 
-// Stored score of pixel p at `threshold`: 0 unless 9 contiguous ring pixels are all brighter than
-// v+t or all darker than v-t; then S = max(A_dark, A_bright) - 1 with A = max over the 16 arcs of
-// the minimum of (v - ring) resp. (ring - v).  `raw` returns S+1 semantics for the no-NMS mode:
-// out_corner says whether the pixel is a corner at all.
-__device__ __forceinline__ int fast_stored_score(const uint8_t* p, long long pitch, int t, bool& corner) {
+typedef short fast_s2 __attribute__((ext_vector_type(2)));
+
+// max over the 16 arcs of 9 contiguous ring pixels of the arc minimum of (v - ring) [low half] and
+// of (ring - v) [high half]: the two "A" values of cv::FAST's cornerScore, by window doubling.
+__device__ __forceinline__ void fast_arc_scores(const fl_u8* p, int pitch, int& a_dark, int& a_bright) {
     const int v = p[0];
-    int d[16];
-    unsigned mb = 0, md = 0;
+    fast_s2 e[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        d[k] = v - ring_px(p, pitch, k);
-        md |= (unsigned)(d[k] > t) << k;
-        mb |= (unsigned)(d[k] < -t) << k;
+        const int r = p[ring_dy(k) * pitch + ring_dx(k)];
+        e[k] = fast_s2{(short)(v - r), (short)(r - v)};
     }
-    auto run9 = [](unsigned m) {
-        const unsigned m2 = m & rot16(m, 1);
-        const unsigned m4 = m2 & rot16(m2, 2);
-        const unsigned m8 = m4 & rot16(m4, 4);
-        return (m8 & rot16(m, 8)) != 0;
-    };
-    corner = run9(md) || run9(mb);
-    if (!corner) return 0;
-    int ad = -256, ab = -256;
+    fast_s2 m2[16], m4[16], m8[16];
 #pragma unroll
-    for (int s = 0; s < 16; s++) {
-        int mn = d[s], mx = d[s];
+    for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 15]);
 #pragma unroll
-        for (int j = 1; j < 9; j++) { const int q = d[(s + j) & 15]; mn = min(mn, q); mx = max(mx, q); }
-        ad = max(ad, mn); ab = max(ab, -mx);
-    }
-    return max(t, max(ad, ab)) - 1;   // cornerScore<16>: seeded with the threshold
+    for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+    fast_s2 best = fast_s2{(short)-512, (short)-512};
+#pragma unroll
+    for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], e[(k + 8) & 15]));
+    a_dark = best.x; a_bright = best.y;
 }
 
 __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     const uint8_t* __restrict__ frames, int w, int h, long long pitch, long long frame_stride,
-    int threshold, int nonmax, int R, int keycap_wave, int nbands, int cap, unsigned* __restrict__ scratch) {
+    int threshold, int nonmax, int R, int spitch, int nbands, int cap, unsigned* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint8_t* sc = smem;                                        // (R+2) x w stored scores
-    const size_t sc_bytes = ((size_t)(R + 2) * w + 15) / 16 * 16;
-    unsigned* keys = reinterpret_cast<unsigned*>(smem + sc_bytes);   // 4 x keycap_wave
     __shared__ int wave_cnt[4];
     __shared__ int pool_off;
+    fl_u8* sc = (fl_u8*)smem;                                    // (R+2) x spitch stored scores; column x at byte x + 4
+    fl_u8* px = sc + (size_t)(R + 2) * spitch;                   // (R+8) x FAST_PPITCH pixels of the current chunk
+    fl_u16* lists = (fl_u16*)(px + (size_t)(R + 8) * FAST_PPITCH);   // 4 x (8 rows x 256) candidate slots
 
     const int band = blockIdx.x, frame = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t* im = frames + (long long)frame * frame_stride;
-    const int y0 = band * R;                                   // first row of the band
+    const int y0 = band * R;                                     // first image row of the band
     unsigned* fs = scratch + (size_t)frame * fast_frame_words(nbands, cap);
+    const bool aligned = ((reinterpret_cast<unsigned long long>(frames) | (unsigned long long)pitch | (unsigned long long)frame_stride) & 3ull) == 0;
+    const int t = threshold;
 
-    // phase A: stored score of band rows -1 .. R (tile row r <-> image row y0 - 1 + r)
-    const int ntile = (R + 2) * w;
-    for (int i = tid; i < ntile; i += FAST_WG) {
-        const int r = i / w, x = i - r * w;
-        const int y = y0 - 1 + r;
-        int s = 0;
-        if (y >= 3 && y < h - 3 && x >= 3 && x < w - 3) {
-            bool corner;
-            s = fast_stored_score(im + (long long)y * pitch + x, pitch, threshold, corner);
-            if (!nonmax) s = corner ? (s + 1) : 0;             // keep "is a corner" distinguishable from score 0
-        }
-        sc[i] = (uint8_t)s;
+    {   // zero the score tile
+        fl_u32* z = (fl_u32*)sc;
+        const int n = ((R + 2) * spitch) >> 2;
+        for (int i = tid; i < n; i += FAST_WG) z[i] = 0u;
     }
-    __syncthreads();
 
-    // phase B: each wavefront walks its R/4 rows in row-major order, 64 pixels at a time
-    const int rows_w = R / 4;
-    unsigned* mykeys = keys + (size_t)wid * keycap_wave;
-    int cnt = 0;
-    for (int rr = 0; rr < rows_w; rr++) {
-        const int ry = wid * rows_w + rr;                      // row inside the band
-        const int y = y0 + ry;
-        if (y < 3 || y >= h - 3) continue;                     // wave-uniform
-        const uint8_t* row = sc + (size_t)(ry + 1) * w;
-        for (int xb = 3; xb < w - 3; xb += 64) {
-            const int x = xb + lane;
-            bool keep = false;
-            int s = 0;
-            if (x < w - 3) {
-                s = row[x];
-                if (nonmax) {
-                    keep = s > 0 || false;
-                    // a corner with stored score 0 can never be strictly greater than its
-                    // neighbours' stored scores (>= 0), so s > 0 is necessary
-                    keep = keep && s > row[x - 1] && s > row[x + 1] &&
-                           s > row[x - w - 1] && s > row[x - w] && s > row[x - w + 1] &&
-                           s > row[x + w - 1] && s > row[x + w] && s > row[x + w + 1];
-                } else {
-                    keep = s > 0;
-                    s -= 1;
+    const int srows = R + 2;                                     // score rows: image rows y0-1 .. y0+R
+    const int rows_per_wave = srows >> 2;
+    fl_u16* mylist = lists + wid * (8 * 256);
+    for (int cx = 0; cx < w; cx += FAST_CHUNK) {
+        __syncthreads();                                         // previous chunk's readers are done (and the zeroing)
+        // ---- stage pixels: tile row r <-> image row y0 - 4 + r, tile byte c <-> image column cx - 4 + c
+        for (int i = tid; i < (R + 8) * (FAST_PPITCH / 4); i += FAST_WG) {
+            const int r = i / (FAST_PPITCH / 4), c = i - r * (FAST_PPITCH / 4);
+            const int y = y0 - 4 + r, x = cx - 4 + 4 * c;
+            unsigned v = 0;
+            if (y >= 0 && y < h && x + 3 >= 0 && x < w) {
+                const uint8_t* src = im + (long long)y * pitch + x;
+                if (aligned && x >= 0 && x + 3 < w) v = *reinterpret_cast<const unsigned*>(src);
+                else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (x + b >= 0 && x + b < w) v |= (unsigned)src[b] << (8 * b);
                 }
             }
-            const unsigned long long bal = __ballot(keep);
-            if (keep) {
-                const int pos = cnt + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pos < keycap_wave) mykeys[pos] = ((unsigned)(ry * w + x) << 8) | (unsigned)s;
+            reinterpret_cast<fl_u32*>(px)[i] = v;
+        }
+        __syncthreads();
+        // ---- phase 1 + 2: each wavefront takes rows_per_wave score rows of this chunk
+        int n = 0;                                               // candidates of this wavefront in this chunk
+        for (int rr = 0; rr < rows_per_wave; rr++) {
+            const int ry = wid * rows_per_wave + rr;             // score row; image row y0 - 1 + ry; pixel tile row ry + 3
+            const int y = y0 - 1 + ry;
+            if (y < 3 || y >= h - 3) continue;                   // wave-uniform
+            const int x0 = cx + 4 * lane;                        // first of the lane's 4 pixels
+            unsigned cand = 0;
+#ifdef FAST_DIAG_SKIP_P1
+            if (x0 < -w) {
+#else
+            if (x0 < w) {
+#endif
+                // window rows dy = -3..3: dwords at tile bytes 4*lane, +4, +8 (image columns x0-4 .. x0+7)
+                unsigned A[7], B[7], Cw[7];
+#pragma unroll
+                for (int d = 0; d < 7; d++) {
+                    const fl_u32* row = reinterpret_cast<const fl_u32*>(px + (ry + d) * FAST_PPITCH) + lane;
+                    A[d] = row[0]; B[d] = row[1]; Cw[d] = row[2];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int v = win_byte(A[3], B[3], Cw[3], 4 + j);
+                    // every opposite pair must have a member brighter than v+t (resp. darker than v-t):
+                    // min over pairs of the pair maximum > v+t, max over pairs of the pair minimum < v-t
+                    int mn_of_mx = 255, mx_of_mn = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int r0 = win_byte(A[3 + ring_dy(k)], B[3 + ring_dy(k)], Cw[3 + ring_dy(k)], 4 + j + ring_dx(k));
+                        const int r1 = win_byte(A[3 + ring_dy(k + 8)], B[3 + ring_dy(k + 8)], Cw[3 + ring_dy(k + 8)], 4 + j + ring_dx(k + 8));
+                        mn_of_mx = min(mn_of_mx, max(r0, r1));
+                        mx_of_mn = max(mx_of_mn, min(r0, r1));
+                    }
+                    const bool bright = mn_of_mx > v + t, dark = mx_of_mn < v - t;
+                    const int x = x0 + j;
+                    if ((bright || dark) && x >= 3 && x < w - 3) cand |= 1u << j;
+                }
             }
-            cnt += __popcll(bal);
+            // append the candidates of these 256 pixels to the wavefront's list: (score row << 8) | column
+            if (__ballot(cand != 0u) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool c = (cand >> j) & 1u;
+                    const unsigned long long bal = __ballot(c);
+                    if (c) mylist[n + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((rr << 8) | (4 * lane + j));
+                    n += __popcll(bal);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef FAST_DIAG_SKIP_P2
+        n = 0;
+#endif
+        for (int i = lane; i < n; i += 64) {
+            const int e = mylist[i];
+            const int lx = e & 255, ry = wid * rows_per_wave + (e >> 8);
+            int ad, ab;
+            fast_arc_scores(px + (ry + 3) * FAST_PPITCH + 4 + lx, FAST_PPITCH, ad, ab);
+            const int a = max(ad, ab);
+            if (a > t) sc[ry * spitch + 4 + cx + lx] = (unsigned char)(nonmax ? a - 1 : a);   // no NMS: score + 1 marks a corner
         }
     }
-    if (lane == 0) wave_cnt[wid] = min(cnt, keycap_wave);
     __syncthreads();
-    const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
-    const int total = c0 + c1 + c2 + c3;
-    if (tid == 0) {
-        int off = 0;
-        if (total > 0) off = (int)atomicAdd(&fs[0], (unsigned)total);
-        pool_off = off;
-        const int nb4 = (nbands + 3) / 4 * 4;
-        fs[4 + band] = (unsigned)off;
-        fs[4 + nb4 + band] = (unsigned)total;
-    }
-    __syncthreads();
-    const int off = pool_off;
+
+    // ---- phase 3: non-max suppression and ordered compaction; pass 0 counts, pass 1 writes
+    const int r_lo = (R * wid) >> 2, r_hi = (R * (wid + 1)) >> 2;   // this wavefront's band rows
     unsigned* pool = fs + 4 + 2 * ((nbands + 3) / 4 * 4);
-    const int wofs = (wid == 0) ? 0 : (wid == 1) ? c0 : (wid == 2) ? c0 + c1 : c0 + c1 + c2;
-    const int mycnt = wave_cnt[wid];
-    for (int i = lane; i < mycnt; i += 64) {
-        const int dst = off + wofs + i;
-        if (dst < cap) pool[dst] = mykeys[i];
+    fl_u8* flags = px;                                           // the pixel chunk and the lists are free now
+    const int fpitch = spitch >> 2;
+    int base = 0;
+#ifdef FAST_DIAG_SKIP_P3
+    if (w > 0) return;
+#endif
+    for (int pass = 0; pass < 2; pass++) {
+        int cnt = 0;
+        for (int ry = r_lo; ry < r_hi; ry++) {
+            const int y = y0 + ry;
+            if (y < 3 || y >= h - 3) continue;                   // wave-uniform
+            const fl_u8* row = sc + (ry + 1) * spitch + 4;       // score row of image row y, column 0
+            for (int xb = 0; xb < w; xb += FAST_CHUNK) {
+                const int x0 = xb + 4 * lane;
+                fl_u8* flag = flags + ry * fpitch + (x0 >> 2);   // pass 0 leaves the lane's 4 keep bits here
+                unsigned c4 = 0, keep = 0;
+                if (pass == 1) {
+                    if (x0 < w) keep = *flag;
+                    if (__ballot(keep != 0u) == 0ull) continue;
+                    if (keep) c4 = *reinterpret_cast<const fl_u32*>(row + x0);
+                } else {
+                    if (x0 < w) c4 = *reinterpret_cast<const fl_u32*>(row + x0);
+                    if (__ballot(c4 != 0u) == 0ull) {
+                        if (x0 < w) *flag = 0;
+                        continue;
+                    }
+                    if (c4 != 0u) {
+                        if (nonmax) {
+                            unsigned U[3], M[3], D[3];
+#pragma unroll
+                            for (int q = 0; q < 3; q++) {
+                                U[q] = *reinterpret_cast<const fl_u32*>(row - spitch + x0 - 4 + 4 * q);
+                                M[q] = *reinterpret_cast<const fl_u32*>(row + x0 - 4 + 4 * q);
+                                D[q] = *reinterpret_cast<const fl_u32*>(row + spitch + x0 - 4 + 4 * q);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int s = win_byte(M[0], M[1], M[2], 4 + j);
+                                int nb = 0;                      // largest of the 8 neighbours
+#pragma unroll
+                                for (int dx = -1; dx <= 1; dx++) {
+                                    nb = max(nb, max(win_byte(U[0], U[1], U[2], 4 + j + dx), win_byte(D[0], D[1], D[2], 4 + j + dx)));
+                                    if (dx != 0) nb = max(nb, win_byte(M[0], M[1], M[2], 4 + j + dx));
+                                }
+                                if (s > nb) keep |= 1u << j;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if ((c4 >> (8 * j)) & 0xffu) keep |= 1u << j;
+                        }
+                    }
+                    if (x0 < w) *flag = (unsigned char)keep;
+                }
+                // row-major order inside the chunk = lane-major, then j
+                int before = 0, total = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned long long bal = __ballot((keep >> j) & 1u);
+                    before += __popcll(bal & ((1ull << lane) - 1ull));
+                    total += __popcll(bal);
+                }
+                if (pass == 1 && keep) {
+                    int pos = base + cnt + before;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((keep >> j) & 1u) {
+                            const unsigned s = (c4 >> (8 * j)) & 0xffu;
+                            if (pos < cap) pool[pos] = ((unsigned)(ry * w + x0 + j) << 8) | (nonmax ? s : s - 1u);
+                            pos++;
+                        }
+                }
+                cnt += total;
+            }
+        }
+        if (pass == 0) {
+            if (lane == 0) wave_cnt[wid] = cnt;
+            __syncthreads();
+            const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+            const int total = c0 + c1 + c2 + c3;
+            if (tid == 0) {
+                int off = 0;
+                if (total > 0) off = (int)atomicAdd(&fs[0], (unsigned)total);
+                pool_off = off;
+                const int nb4 = (nbands + 3) / 4 * 4;
+                fs[4 + band] = (unsigned)off;
+                fs[4 + nb4 + band] = (unsigned)total;
+            }
+            __syncthreads();
+            base = pool_off + ((wid == 0) ? 0 : (wid == 1) ? c0 : (wid == 2) ? c0 + c1 : c0 + c1 + c2);
+            if (total == 0) break;
+        }
     }
 }
 
@@ -211,8 +347,7 @@ __global__ __launch_bounds__(FAST_WG) void fast_gather_kernel(int w, int R, int 
 extern "C" size_t slam_hip_fast_scratch_bytes(int w, int h, int nframes, int cap_per_frame) {
     FastPlan p;
     if (w < 1 || h < 1 || nframes < 1 || cap_per_frame < 1) return 0;
-    // the no-NMS plan has the smaller bands, i.e. the larger band tables: size for it
-    if (!fast_plan(w, h, 0, p)) return 0;
+    if (!fast_plan(w, h, p)) return 0;
     return fast_frame_words(p.nbands, cap_per_frame) * 4 * (size_t)nframes;
 }
 
@@ -226,7 +361,7 @@ extern "C" int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, in
         cap_per_frame > (1 << 26))
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: bad arguments");
     FastPlan p;
-    if (!fast_plan(w, h, nonmax != 0, p))
+    if (!fast_plan(w, h, p))
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: image too wide (%d) for the band kernel", w);
     const size_t need = fast_frame_words(p.nbands, cap_per_frame) * 4 * (size_t)nframes;
     if (scratch_bytes < need || ((uintptr_t)d_scratch & 15))
@@ -237,7 +372,7 @@ extern "C" int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, in
     SLAM_HIP_CHECK(ctx, hipMemset2DAsync(d_scratch, fast_frame_words(p.nbands, cap_per_frame) * 4, 0, 16, (size_t)nframes, ctx->stream));
     hipLaunchKernelGGL(fast_band_kernel, dim3(p.nbands, nframes), dim3(FAST_WG), p.lds_bytes, ctx->stream,
                        d_frames, w, h, (long long)pitch, (long long)frame_stride, threshold, nonmax ? 1 : 0,
-                       p.R, p.keycap_wave, p.nbands, cap_per_frame, (unsigned*)d_scratch);
+                       p.R, p.spitch, p.nbands, cap_per_frame, (unsigned*)d_scratch);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(fast_gather_kernel, dim3(nframes), dim3(FAST_WG), 0, ctx->stream, w, p.R, p.nbands,
                        cap_per_frame, (const unsigned*)d_scratch, d_out, d_counts);
