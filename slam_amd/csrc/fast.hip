@@ -132,20 +132,34 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     for (int cx = 0; cx < w; cx += FAST_CHUNK) {
         __syncthreads();                                         // previous chunk's readers are done (and the zeroing)
         // ---- stage pixels: tile row r <-> image row y0 - 4 + r, tile byte c <-> image column cx - 4 + c
-        for (int i = tid; i < (R + 8) * (FAST_PPITCH / 4); i += FAST_WG) {
-            const int r = i / (FAST_PPITCH / 4), c = i - r * (FAST_PPITCH / 4);
-            const int y = y0 - 4 + r, x = cx - 4 + 4 * c;
-            unsigned v = 0;
-            if (y >= 0 && y < h && x + 3 >= 0 && x < w) {
-                const uint8_t* src = im + (long long)y * pitch + x;
-                if (aligned && x >= 0 && x + 3 < w) v = *reinterpret_cast<const unsigned*>(src);
-                else {
+        // (loads of a batch are all issued before the first LDS write: one memory round trip per batch)
+        constexpr int NB = 6;
+        const int ndw = (R + 8) * (FAST_PPITCH / 4);
+        for (int base = tid; base < ndw; base += FAST_WG * NB) {
+            unsigned v[NB];
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (x + b >= 0 && x + b < w) v |= (unsigned)src[b] << (8 * b);
+            for (int u = 0; u < NB; u++) {
+                const int i = base + u * FAST_WG;
+                v[u] = 0;
+                if (i < ndw) {
+                    const int r = i / (FAST_PPITCH / 4), c = i - r * (FAST_PPITCH / 4);
+                    const int y = y0 - 4 + r, x = cx - 4 + 4 * c;
+                    if (y >= 0 && y < h && x + 3 >= 0 && x < w) {
+                        const uint8_t* src = im + (long long)y * pitch + x;
+                        if (aligned && x >= 0 && x + 3 < w) v[u] = *reinterpret_cast<const unsigned*>(src);
+                        else {
+#pragma unroll
+                            for (int b = 0; b < 4; b++)
+                                if (x + b >= 0 && x + b < w) v[u] |= (unsigned)src[b] << (8 * b);
+                        }
+                    }
                 }
             }
-            reinterpret_cast<fl_u32*>(px)[i] = v;
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int i = base + u * FAST_WG;
+                if (i < ndw) reinterpret_cast<fl_u32*>(px)[i] = v[u];
+            }
         }
         __syncthreads();
         // ---- phase 1 + 2: each wavefront takes rows_per_wave score rows of this chunk

@@ -27,6 +27,7 @@ struct PyrLevelArgs {
     int rb, nband;      // output rows per tile, tiles per column
     int span;           // bytes of one staged source row in LDS (multiple of 4)
     int unit0;          // first work unit of this level within a frame
+    int box;            // 0, or s in {2,4,8}: every tap pair is (s*d + s/2 - 1, +1) with equal weights
 };
 
 struct PyrArgs {
@@ -35,6 +36,55 @@ struct PyrArgs {
     int sw, sh, nframes, nlev, units;
     PyrLevelArgs lev[SLAM_HIP_MAX_LEVELS];
 };
+
+// Exact integer reduction by S in {2,4,8} when every weight is 1/2: the resize formula collapses to
+//   out = (S[r][c] + S[r][c+1] + S[r+1][c] + S[r+1][c+1] + 2) >> 2,  r = S*dy + S/2 - 1, c = S*dx + S/2 - 1
+// (with all four 11-bit weights equal to 1024 the two >>16 steps are exact).  Each thread produces 4
+// adjacent output pixels from 4*S contiguous source bytes of two rows; xn is a multiple of 4 and the
+// source is 16-byte aligned (checked on the host).
+template <int S>
+__device__ __forceinline__ void box_tile(const uint8_t* __restrict__ src, long long spitch, uint8_t* __restrict__ dst,
+                                         long long dpitch, int xb, int xn, int yb, int yn) {
+    const int ncg = xn >> 2;
+    const int items = yn * ncg;
+    const float rncg = 1.0f / (float)ncg;
+    for (int item = threadIdx.x; item < items; item += 256) {
+        const int row = (int)(((float)item + 0.5f) * rncg);           // items <= 2^13: exact
+        const int cg = item - row * ncg;
+        const uint8_t* r0 = src + (long long)(S * (yb + row) + S / 2 - 1) * spitch + (long long)S * (xb + 4 * cg);
+        const uint8_t* r1 = r0 + spitch;
+        uint32_t packed;
+        if (S == 2) {
+            const uint2 u = *reinterpret_cast<const uint2*>(r0), v = *reinterpret_cast<const uint2*>(r1);
+            // 16-bit lanes: sums of byte pairs
+            const uint32_t ex = (u.x & 0x00ff00ffu) + ((u.x >> 8) & 0x00ff00ffu) + (v.x & 0x00ff00ffu) + ((v.x >> 8) & 0x00ff00ffu) + 0x00020002u;
+            const uint32_t ey = (u.y & 0x00ff00ffu) + ((u.y >> 8) & 0x00ff00ffu) + (v.y & 0x00ff00ffu) + ((v.y >> 8) & 0x00ff00ffu) + 0x00020002u;
+            const uint32_t qx = (ex >> 2) & 0x00ff00ffu, qy = (ey >> 2) & 0x00ff00ffu;
+            packed = (qx & 0xffu) | ((qx >> 8) & 0xff00u) | ((qy & 0xffu) << 16) | ((qy >> 16) << 24);
+        } else if (S == 4) {
+            const uint4 u = *reinterpret_cast<const uint4*>(r0), v = *reinterpret_cast<const uint4*>(r1);
+            const uint32_t a[4] = {u.x, u.y, u.z, u.w}, b[4] = {v.x, v.y, v.z, v.w};
+            packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = ((a[j] >> 8) & 0xffu) + ((a[j] >> 16) & 0xffu) + ((b[j] >> 8) & 0xffu) + ((b[j] >> 16) & 0xffu) + 2u;
+                packed |= (t >> 2) << (8 * j);
+            }
+        } else {
+            const uint4 u0 = reinterpret_cast<const uint4*>(r0)[0], u1 = reinterpret_cast<const uint4*>(r0)[1];
+            const uint4 v0 = reinterpret_cast<const uint4*>(r1)[0], v1 = reinterpret_cast<const uint4*>(r1)[1];
+            const uint32_t a[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            const uint32_t b[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = (a[2 * j] >> 24) + (a[2 * j + 1] & 0xffu) + (b[2 * j] >> 24) + (b[2 * j + 1] & 0xffu) + 2u;
+                packed |= (t >> 2) << (8 * j);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(dst + (long long)(yb + row) * dpitch + xb + 4 * cg) = packed;
+    }
+}
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void pyr_build_kernel(PyrArgs a) {
@@ -52,7 +102,15 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(PyrArgs a) {
     const int band = local / L.ncolt, colt = local - band * L.ncolt;
     const int xb = colt * L.xt, xn = min(L.xt, L.dw - xb);
     const int yb = band * L.rb, yn = min(L.rb, L.dh - yb);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
+    if (L.box) {        // exact 2x / 4x / 8x reduction: straight from global memory, no LDS
+        const uint8_t* S = a.src + (long long)frame * a.sstride;
+        uint8_t* D = L.dst + (long long)frame * L.dstride;
+        if (L.box == 2) box_tile<2>(S, a.spitch, D, L.dpitch, xb, xn, yb, yn);
+        else if (L.box == 4) box_tile<4>(S, a.spitch, D, L.dpitch, xb, xn, yb, yn);
+        else box_tile<8>(S, a.spitch, D, L.dpitch, xb, xn, yb, yn);
+        return;
+    }
     const int span = L.span;
     const int cx0 = L.xofs[xb] & ~3;                                   // first staged source column
     const int ndw = min(span, ((a.sw + 3) & ~3) - cx0) >> 2;           // dwords staged per row
@@ -60,6 +118,8 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(PyrArgs a) {
     unsigned char* rows = pyr_lds;
     uint2* xtab = reinterpret_cast<uint2*>(pyr_lds + ((2 * L.rb * span + 7) & ~7));
     uint32_t* ytab = reinterpret_cast<uint32_t*>(xtab + ((L.xt + 3) & ~3));
+
+    int* rowidx = reinterpret_cast<int*>(ytab + L.rb);                  // clamped source row of each staged row
 
     const int xpad = (xn + 3) & ~3;
     for (int i = tid; i < xpad; i += 256) {
@@ -69,23 +129,36 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(PyrArgs a) {
         xtab[i] = make_uint2(o | (o1 << 16), L.xcoef[dx]);
     }
     if (tid < yn) ytab[tid] = L.ycoef[yb + tid];
+    if (tid < 2 * yn) rowidx[tid] = min(max(L.yofs[yb + (tid >> 1)] + (tid & 1), 0), a.sh - 1);
+    __syncthreads();
 
+    // source rows -> LDS.  Every load of a batch is issued (unconditionally, on a clamped index) before
+    // the first LDS write, so a thread waits for one memory round trip per batch, not one per dword.
     const uint8_t* S = a.src + (long long)frame * a.sstride;
-    for (int k = wave; k < 2 * yn; k += 4) {
-        const int r = min(max(L.yofs[yb + (k >> 1)] + (k & 1), 0), a.sh - 1);
-        const uint8_t* R = S + (long long)r * a.spitch + cx0;
-        uint32_t* dstrow = reinterpret_cast<uint32_t*>(rows + k * span);
-        for (int c = lane; c < ndw; c += 64) {
-            uint32_t v;
+    const int total = 2 * yn * ndw;
+    const float rndw = 1.0f / (float)ndw;
+    constexpr int NB = 12;
+    for (int base = tid; base < total; base += 256 * NB) {
+        uint32_t v[NB];
+        int dsto[NB];
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int idx = min(base + u * 256, total - 1);
+            const int k = (int)(((float)idx + 0.5f) * rndw);               // idx < 2^16: exact
+            const int c = idx - k * ndw;
+            const uint8_t* R = S + (long long)rowidx[k] * a.spitch + cx0;
+            dsto[u] = k * span + 4 * c;
             if (ALIGNED) {
-                v = *reinterpret_cast<const uint32_t*>(R + 4 * c);
-            } else {                                                   // any pitch / base: byte loads, clamped
+                v[u] = *reinterpret_cast<const uint32_t*>(R + 4 * c);
+            } else {                                                       // any pitch / base: byte loads, clamped
                 const int lim = a.sw - 1 - cx0;
-                v = (uint32_t)R[min(4 * c, lim)] | ((uint32_t)R[min(4 * c + 1, lim)] << 8) |
-                    ((uint32_t)R[min(4 * c + 2, lim)] << 16) | ((uint32_t)R[min(4 * c + 3, lim)] << 24);
+                v[u] = (uint32_t)R[min(4 * c, lim)] | ((uint32_t)R[min(4 * c + 1, lim)] << 8) |
+                       ((uint32_t)R[min(4 * c + 2, lim)] << 16) | ((uint32_t)R[min(4 * c + 3, lim)] << 24);
             }
-            dstrow[c] = v;
         }
+#pragma unroll
+        for (int u = 0; u < NB; u++)
+            if (base + u * 256 < total) *reinterpret_cast<uint32_t*>(rows + dsto[u]) = v[u];
     }
     __syncthreads();
 
@@ -119,7 +192,7 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(PyrArgs a) {
 const int PYR_LDS_BUDGET = 40 * 1024;
 
 int pyr_lds_bytes(int rb, int xt, int span) {
-    return ((2 * rb * span + 7) & ~7) + ((xt + 3) & ~3) * 8 + rb * 4;
+    return ((2 * rb * span + 7) & ~7) + ((xt + 3) & ~3) * 8 + rb * 4 + 2 * rb * 4;   // rows, xtab, ytab, rowidx
 }
 
 // Largest staged row span (bytes, multiple of 4) over the column tiles of width xt.
@@ -135,6 +208,20 @@ int pyr_span(const std::vector<int32_t>& xofs, int sw, int dw, int xt) {
 }
 
 }  // namespace
+
+// s in {2,4,8} when the level is an exact reduction by s whose tap tables are regular (offset
+// s*d + s/2 - 1, both weights 1024) and whose width allows whole-dword groups; else 0.
+int slam_pyr_detect_box(const std::vector<int32_t>& xofs, const std::vector<uint32_t>& xcoef,
+                        const std::vector<int32_t>& yofs, const std::vector<uint32_t>& ycoef,
+                        int sw, int sh, int dw, int dh) {
+    if (dw < 4 || (dw & 3) || sw % dw || sh % dh || sw / dw != sh / dh) return 0;
+    const int s = sw / dw;
+    if (s != 2 && s != 4 && s != 8) return 0;
+    const uint32_t half = 1024u | (1024u << 16);
+    for (int d = 0; d < dw; d++) if (xofs[d] != s * d + s / 2 - 1 || xcoef[d] != half) return 0;
+    for (int d = 0; d < dh; d++) if (yofs[d] != s * d + s / 2 - 1 || ycoef[d] != half) return 0;
+    return s;
+}
 
 // Tile shape of one resized level: as many output rows / columns per workgroup as fit the LDS budget.
 int slam_pyr_plan_level(const std::vector<int32_t>& xofs, int sw, int dw, int dh, slam_pyr_plan* out) {
@@ -173,6 +260,7 @@ int pyr_launch(slam_ctx* ctx, const uint8_t* src, int sw, int sh, size_t spitch,
         L.dw = lev[l].dw; L.dh = lev[l].dh;
         L.xt = lev[l].plan.xt; L.ncolt = lev[l].plan.ncolt; L.rb = lev[l].plan.rb; L.nband = lev[l].plan.nband;
         L.span = lev[l].plan.span; L.unit0 = units;
+        L.box = (lev[l].plan.box && ((((uintptr_t)src | spitch | sstride) & 15) == 0)) ? lev[l].plan.box : 0;
         units += L.ncolt * L.nband;
         lds = std::max(lds, lev[l].plan.lds);
     }
@@ -248,6 +336,7 @@ extern "C" int slam_hip_pyramid_create(slam_ctx* ctx, int w, int h, int nlev, co
         if (slam_pyr_plan_level(xo, w, dw, dh, &p->plan[l]) != SLAM_HIP_OK) {
             rc = slam_set_error(ctx, SLAM_HIP_EINVAL, "pyramid_create: level %d cannot be tiled", l); break;
         }
+        p->plan[l].box = slam_pyr_detect_box(xo, xc, yo, yc, w, h, dw, dh);
         void* ptr = nullptr;
         auto alloc_copy = [&](const void* src, size_t bytes, void** dptr) -> int {
             hipError_t e = hipMalloc(dptr, bytes);
@@ -388,6 +477,7 @@ extern "C" int slam_hip_debug_resize(slam_ctx* ctx, const uint8_t* src, int sw, 
     PyrLevelHost lev{base + off_dst, dp, 0, dw, dh, d_xo, d_xc, d_yo, d_yc, {}};
     if (slam_pyr_plan_level(xo, sw, dw, dh, &lev.plan) != SLAM_HIP_OK)
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "debug_resize: cannot be tiled");
+    lev.plan.box = slam_pyr_detect_box(xo, xc, yo, yc, sw, sh, dw, dh);
     rc = pyr_launch(ctx, base + off_src, sw, sh, (size_t)sw, 0, 1, &lev, 1);
     if (rc != SLAM_HIP_OK) return rc;
     SLAM_HIP_CHECK(ctx, hipMemcpy2DAsync(dst, dpitch, base + off_dst, dp, dw, dh, hipMemcpyDeviceToHost, ctx->stream));

@@ -41,6 +41,7 @@ struct slam_pyr_dev {
 // Tile shape of the pyramid kernel for one resized level.
 struct slam_pyr_plan {
     int xt = 0, ncolt = 0, rb = 0, nband = 0, span = 0, lds = 0;
+    int box = 0;    // 2, 4 or 8: exact integer reduction with regular taps (box-filter path)
 };
 
 struct slam_pyr {
@@ -84,6 +85,9 @@ void slam_resize_tables(int ssize, int dsize, std::vector<int32_t>& ofs, std::ve
 // kernels' host launchers (defined in the .hip files)
 int slam_launch_pyramid(slam_ctx* ctx, slam_pyr* pyr);
 int slam_pyr_plan_level(const std::vector<int32_t>& xofs, int sw, int dw, int dh, slam_pyr_plan* out);
+int slam_pyr_detect_box(const std::vector<int32_t>& xofs, const std::vector<uint32_t>& xcoef,
+                        const std::vector<int32_t>& yofs, const std::vector<uint32_t>& ycoef,
+                        int sw, int sh, int dw, int dh);
 
 static_assert(sizeof(slam_match_job) == 72 && sizeof(slam_match_result) == 24, "ABI struct layout");
 static_assert(sizeof(slam_track_job) == 48 && sizeof(slam_track_result) == 28, "ABI struct layout");
