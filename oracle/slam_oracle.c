@@ -493,18 +493,46 @@ int so_get_sorted_keypoints(const uint8_t* im, int w, int h, ptrdiff_t pitch, si
 /* tests/test_matching.cpp:13-101 restated                                                    */
 /* ------------------------------------------------------------------------------------------ */
 
-void so_proptest_srand(unsigned seed) { srand(seed); }
+/* glibc's rand() (the TYPE_3 additive feedback generator r[i] = r[i-3] + r[i-31], seeded through
+ * the 16807 Lehmer generator, first 310 outputs discarded), kept in private state: the trial stream
+ * of tests/test_matching.cpp is the unseeded (seed 1) glibc stream, and a private copy cannot be
+ * disturbed by other users of rand() in the process (runtime libraries, other threads). */
+static uint32_t pt_r[34];
+static int pt_f = 3, pt_b = 0, pt_seeded = 0;
+
+void so_proptest_srand(unsigned seed) {
+    int32_t word = seed ? (int32_t)seed : 1;
+    pt_r[0] = (uint32_t)word;
+    for (int i = 1; i < 31; i++) {
+        const long hi = word / 127773, lo = word % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        word = (int32_t)w;
+        pt_r[i] = (uint32_t)word;
+    }
+    pt_f = 3; pt_b = 0; pt_seeded = 1;
+    for (int i = 0; i < 310; i++) (void)so_proptest_rand();
+}
+
+int so_proptest_rand(void) {
+    if (!pt_seeded) so_proptest_srand(1);
+    pt_r[pt_f] += pt_r[pt_b];
+    const uint32_t out = pt_r[pt_f] >> 1;
+    if (++pt_f >= 31) pt_f = 0;
+    if (++pt_b >= 31) pt_b = 0;
+    return (int)out;
+}
 
 void so_proptest_next(int use_area_mask, int use_patch_mask, so_proptest_case* c) {
     memset(c, 0, sizeof(*c));
     /* tests/test_matching.cpp:15-17.  The order in which the two rand() calls of one constructor
      * call are evaluated is unspecified in C++; g++ (the reference's compiler, Makefile:1)
      * evaluates call arguments right to left, which is what is done here. */
-    const int hh = rand() % 1000 + 1;
-    const int ww = rand() % 1000 + 1;
+    const int hh = so_proptest_rand() % 1000 + 1;
+    const int ww = so_proptest_rand() % 1000 + 1;
     c->w = ww; c->h = hh;
-    const int ph = imin(rand() % imin(200, hh) + 1, hh);
-    const int pw = imin(rand() % imin(200, ww) + 1, ww);
+    const int ph = imin(so_proptest_rand() % imin(200, hh) + 1, hh);
+    const int pw = imin(so_proptest_rand() % imin(200, ww) + 1, ww);
     c->pw = pw; c->ph = ph;
     c->im = (uint8_t*)malloc((size_t)ww * hh);
     c->patch = (uint8_t*)malloc((size_t)pw * ph);
@@ -516,8 +544,8 @@ void so_proptest_next(int use_area_mask, int use_patch_mask, so_proptest_case* c
         }
     /* :26-40 */
     const int leftpatch = pw / 2, toppatch = ph / 2;
-    const int xpatch = rand() % ww;
-    const int ypatch = rand() % hh;
+    const int xpatch = so_proptest_rand() % ww;
+    const int ypatch = so_proptest_rand() % hh;
     c->xpatch = xpatch; c->ypatch = ypatch;
     const int ptop = imax(ypatch - toppatch, 0), pleft = imax(xpatch - leftpatch, 0);
     const int pbottom = imin(ypatch - toppatch + ph, hh);
@@ -525,20 +553,20 @@ void so_proptest_next(int use_area_mask, int use_patch_mask, so_proptest_case* c
     const int dptop = ptop - (ypatch - toppatch), dpleft = pleft - (xpatch - leftpatch);
     for (int i = 0; i < pw; ++i)
         for (int j = 0; j < ph; ++j)
-            c->patch[(size_t)j * pw + i] = (uint8_t)(rand() % 255);
+            c->patch[(size_t)j * pw + i] = (uint8_t)(so_proptest_rand() % 255);
     for (int y = ptop; y < pbottom; ++y)
         for (int x = pleft; x < pright; ++x)
             c->patch[(size_t)(dptop + y - ptop) * pw + (dpleft + x - pleft)] = c->im[(size_t)y * ww + x];
     /* :44-46 */
-    const int x0area = xpatch - (rand() % 100), y0area = ypatch - (rand() % 100);
-    const int x1area = xpatch + (rand() % 100) + 1, y1area = ypatch + (rand() % 100) + 1;
+    const int x0area = xpatch - (so_proptest_rand() % 100), y0area = ypatch - (so_proptest_rand() % 100);
+    const int x1area = xpatch + (so_proptest_rand() % 100) + 1, y1area = ypatch + (so_proptest_rand() % 100) + 1;
     c->ax = x0area; c->ay = y0area; c->aw = x1area - x0area; c->ah = y1area - y0area;
     /* :49-58 */
     if (use_area_mask) {
         c->area_mask = (uint8_t*)malloc((size_t)c->aw * c->ah);
         for (int i = 0; i < c->aw; ++i)
             for (int j = 0; j < c->ah; ++j)
-                c->area_mask[(size_t)j * c->aw + i] = ((rand() % 255) > 128) ? 1 : 0;
+                c->area_mask[(size_t)j * c->aw + i] = ((so_proptest_rand() % 255) > 128) ? 1 : 0;
         c->area_mask[(size_t)(ypatch - y0area) * c->aw + (xpatch - x0area)] = 1;
     }
     /* :61-69 */
@@ -546,7 +574,7 @@ void so_proptest_next(int use_area_mask, int use_patch_mask, so_proptest_case* c
         c->patch_mask = (uint8_t*)malloc((size_t)pw * ph);
         for (int i = 0; i < pw; ++i)
             for (int j = 0; j < ph; ++j)
-                c->patch_mask[(size_t)j * pw + i] = ((rand() % 255) > 128) ? 1 : 0;
+                c->patch_mask[(size_t)j * pw + i] = ((so_proptest_rand() % 255) > 128) ? 1 : 0;
     }
 }
 

@@ -108,6 +108,7 @@ typedef struct so_proptest_case {
 } so_proptest_case;
 
 void so_proptest_srand(unsigned seed);   /* the reference never seeds: glibc default = srand(1) */
+int so_proptest_rand(void);              /* next value of the private glibc-compatible rand() stream */
 /* Draws the next trial exactly as tests/test_matching.cpp:15-69 does (same rand() call order). */
 void so_proptest_next(int use_area_mask, int use_patch_mask, so_proptest_case* c);
 void so_proptest_free(so_proptest_case* c);

@@ -147,6 +147,16 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
     return o;
 }
 
+// value of lane `i` (wave-uniform index)
+__device__ __forceinline__ int lane_i32(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
+__device__ __forceinline__ float lane_f32(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
+__device__ __forceinline__ long long lane_i64(long long v, int i) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, i);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), i);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int i) { return __longlong_as_double(lane_i64(__double_as_longlong(v), i)); }
+
 __device__ __forceinline__ bool span_ok(long long off, long long len, unsigned long long total) {
     return off >= 0 && len >= 0 && (unsigned long long)off <= total && (unsigned long long)len <= total - (unsigned long long)off;
 }
@@ -237,39 +247,53 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
 
     STAMP_DECL;
     STAMP(1);
+    // Per-level constants do not depend on the walk's results: lane l computes those of level l once
+    // (template size and cv::resize scales, search radius, window size); the level loop then reads
+    // lane i.  Lanes beyond the last level repeat level 0.
+    const int L = tid < pyr.nlev ? tid : 0;
+    float sub_l = 1.f, subn_l = 1.f;
+    int lw_l = 0, lh_l = 0; long long lp_l = 0, ls_l = 0; const uint8_t* ld_l = nullptr;
+#pragma unroll
+    for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++) {
+        if (l == L) { sub_l = pyr.lev[l].sub; lw_l = pyr.lev[l].w; lh_l = pyr.lev[l].h; lp_l = pyr.lev[l].pitch; ls_l = pyr.lev[l].frame_stride; ld_l = pyr.lev[l].data; }
+        if (l == L + 1) subn_l = pyr.lev[l].sub;
+    }
+    int tw_l = job.projw, th_l = job.projh;      // feature.cpp:126-128
+    double scx_l = 1.0, scy_l = 1.0;
+    if (sub_l != 1.f) {                          // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
+        tw_l = (int)__fdiv_rn((float)job.projw, sub_l);
+        th_l = (int)__fdiv_rn((float)job.projh, sub_l);
+        if (tw_l > 0 && th_l > 0) {
+            scx_l = resize_scale(job.projw, tw_l);
+            scy_l = resize_scale(job.projh, th_l);
+        }
+    }
+    float rad_l;
+    if (L == pyr.nlev - 1) {
+        rad_l = __fdiv_rn(20.f, sub_l);          // feature.cpp:119,134
+    } else {                                     // feature.cpp:136-138: double expression stored to float
+        rad_l = (float)__ddiv_rn(__dmul_rn(1.3, (double)subn_l), (double)sub_l);
+        if (L == 0) rad_l = __fmul_rn(rad_l, (float)job.stride);
+    }
+    const int rs_l = (int)round((double)__fadd_rn(__fmul_rn(2.f, rad_l), 1.f));   // feature.cpp:146
+    const double stop_below = __dmul_rn(0.67, (double)job.threshold);           // feature.cpp:151
+
     float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
     float response = 0.f, sdx = 0.f, sdy = 0.f;
     int levels_run = 0;
     bool empty_level = false;
     for (int i = pyr.nlev - 1; i >= 0; --i) {
-        float sub = 1.f, subnext = 1.f;
-        int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
-#pragma unroll
-        for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++) {
-            if (l == i) { sub = pyr.lev[l].sub; lw = pyr.lev[l].w; lh = pyr.lev[l].h; lp = pyr.lev[l].pitch; ls = pyr.lev[l].frame_stride; ld = pyr.lev[l].data; }
-            if (l == i + 1) subnext = pyr.lev[l].sub;
-        }
-        if (sub == 1.f) {                        // feature.cpp:126-128
-            t.tw = job.projw; t.th = job.projh; t.resized = false;
-        } else {                                 // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
-            t.tw = (int)__fdiv_rn((float)job.projw, sub);
-            t.th = (int)__fdiv_rn((float)job.projh, sub);
-            t.resized = true;
-            if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
-            t.scale_x = resize_scale(job.projw, t.tw);
-            t.scale_y = resize_scale(job.projh, t.th);
-        }
-        float searchRad;
-        if (i == pyr.nlev - 1) {
-            searchRad = __fdiv_rn(20.f, sub);    // feature.cpp:119,134
-        } else {                                 // feature.cpp:136-138: double expression stored to float
-            searchRad = (float)__ddiv_rn(__dmul_rn(1.3, (double)subnext), (double)sub);
-            if (i == 0) searchRad = __fmul_rn(searchRad, (float)job.stride);
-        }
+        const float sub = lane_f32(sub_l, i), searchRad = lane_f32(rad_l, i);
+        const int lw = lane_i32(lw_l, i), lh = lane_i32(lh_l, i), rs = lane_i32(rs_l, i);
+        const long long lp = lane_i64(lp_l, i), ls = lane_i64(ls_l, i);
+        const uint8_t* ld = reinterpret_cast<const uint8_t*>(lane_i64(reinterpret_cast<long long>(ld_l), i));
+        t.tw = lane_i32(tw_l, i); t.th = lane_i32(th_l, i);
+        t.resized = sub != 1.f;
+        if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
+        t.scale_x = lane_f64(scx_l, i); t.scale_y = lane_f64(scy_l, i);
         // feature.cpp:144-146
         const int rx = (int)round((double)__fsub_rn(__fdiv_rn(tx, sub), searchRad));
         const int ry = (int)round((double)__fsub_rn(__fdiv_rn(ty, sub), searchRad));
-        const int rs = (int)round((double)__fadd_rn(__fmul_rn(2.f, searchRad), 1.f));
         const Geo g = make_geo(ld + (long long)job.frame * ls, lw, lh, lp, t.tw, t.th, rx, ry, rs, rs,
                                nullptr, (i == 0) ? 1 : job.stride, true, false);   // feature.cpp:147-149
         int mx = 0, my = 0;
@@ -279,14 +303,13 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (g.reject) { response = -1.f; }       // matching.cpp:26-30
         else {
             // feature.cpp:151-152: the level that ends the walk also reports the sub-pixel fit
-            const double stop_below = __dmul_rn(0.67, (double)job.threshold);
             const CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, i == 0, stop_below STAMP_PASS);
             mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
             STAMP(21);
         }
         tx = __fmul_rn((float)mx, sub);          // feature.cpp:150
         ty = __fmul_rn((float)my, sub);
-        if ((double)response < __dmul_rn(0.67, (double)job.threshold)) break;   // feature.cpp:151-152
+        if ((double)response < stop_below) break;   // feature.cpp:151-152
     }
     STAMP(30);
     if (tid == 0) {

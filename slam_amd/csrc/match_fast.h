@@ -175,7 +175,39 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         __syncthreads();                                   // previous chunk's readers are done
         STAMP(10);
         // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
-        {
+        const int ntap = G * 4 + ur;                       // column taps then row taps, 8 bytes each
+        if (t.resized && ntap * 8 <= lp.tile_bytes) {
+            // cv::resize of the template on the fly (feature.cpp:130-131).  The tap tables of this
+            // chunk go to LDS first (the tile region is still free), then every lane produces one
+            // template pixel at a time: 4 source bytes of the patch, 4 of the mask, fixed-point blend.
+            lds_u64* taps = reinterpret_cast<lds_u64*>(tile);
+            for (int i = lane; i < ntap; i += SLAM_WG) {
+                int o, c0, c1;
+                if (i < G * 4) resize_tap(min(i, g.pw - 1), t.scale_x, t.srcw, true, o, c0, c1);
+                else resize_tap(u0 + (i - G * 4), t.scale_y, t.srch, false, o, c0, c1);
+                taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)o;
+            }
+            __syncthreads();
+            lds_u8* tb = reinterpret_cast<lds_u8*>(tmpl);
+            const int wpx = G * 4;
+            const float rw = __builtin_amdgcn_rcpf((float)wpx);
+            for (int i = lane; i < ur * wpx; i += SLAM_WG) {
+                const int u = (int)(((float)i + 0.5f) * rw), v = i - u * wpx;
+                unsigned p = 0, m = 0;
+                if (v < g.pw) {
+                    const unsigned long long tx = taps[v], ty = taps[wpx + u];
+                    const int sx = (int)(unsigned)tx, sy = (int)(unsigned)ty;
+                    const int a0 = (short)(tx >> 32), a1 = (short)(tx >> 48), b0 = (short)(ty >> 32), b1 = (short)(ty >> 48);
+                    m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, true) != 0) : 1u;
+                    p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, false) * m;
+                }
+                sp_part += p * p;
+                const int e = (u * G + (v >> 2)) * 8 + (v & 3);        // byte of the {P0, mask} entry
+                tb[e] = (unsigned char)p;
+                tb[e + 4] = m ? 0xFF : 0x00;
+            }
+            __syncthreads();                               // the taps are dead before the tile is staged over them
+        } else {
             const Walk2D w = make_walk(G, ur);
             for (int gg = w.c0; gg < G; gg += w.cstep) {
                 const int nb = min(4, g.pw - gg * 4);      // pixels of this group inside the template

@@ -6,25 +6,20 @@
 
 namespace slamhip {
 
-namespace {
-struct ThreadCtx {
-    slam_ctx* ctx = nullptr;
-    ~ThreadCtx() { if (ctx) slam_hip_destroy(ctx); }
-};
-}  // namespace
-
+// One context per host thread, created on first use and deliberately never destroyed: at process
+// exit the HIP runtime may already be shutting down when thread-local destructors run.
 slam_ctx* context() {
-    static thread_local ThreadCtx t;
-    if (!t.ctx) {
+    static thread_local slam_ctx* ctx = nullptr;
+    if (!ctx) {
         const char* d = std::getenv("SLAM_HIP_DEVICE");
         const int dev = d ? std::atoi(d) : 0;
         slam_ctx* c = nullptr;
         const int rc = slam_hip_create(dev, &c);
         if (rc != SLAM_HIP_OK)
             throw std::runtime_error(std::string("slam_hip_create: ") + slam_hip_last_error_string(nullptr));
-        t.ctx = c;
+        ctx = c;
     }
-    return t.ctx;
+    return ctx;
 }
 
 void check(int rc, const char* what) {

@@ -37,6 +37,20 @@ class _Continue:
         return self._p.next()
 
 
+def test_private_rand_stream_is_glibc_rand(oracle):
+    """The trial generator draws from a private copy of glibc's rand(); it must be that stream."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(HERE), "oracle", "_build", "libslam_oracle.so"))
+    lib.so_proptest_rand.restype = ctypes.c_int
+    lib.so_proptest_srand.argtypes = [ctypes.c_uint]
+    for seed in (1, 12345):
+        libc.srand(seed)
+        lib.so_proptest_srand(seed)
+        assert [lib.so_proptest_rand() for _ in range(2000)] == [libc.rand() for _ in range(2000)]
+    lib.so_proptest_srand(1)
+
+
 def test_proptest_image_formula(oracle):
     from slam_amd import synth
     pt = oracle.PropTest(0, 0)
