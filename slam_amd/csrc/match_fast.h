@@ -20,6 +20,9 @@
 // instruction-cache bound if each mode gets its own copy of the staging and scoring code.
 #pragma once
 
+#include <cfloat>
+#include <climits>
+
 #include "match_common.h"
 
 #define FAST_LDS_DEFAULT (16 * 1024)
@@ -312,18 +315,49 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
 
     // ---- scores of the block's cells, running argmax ---------------------------------------------
     if (update) {
-        const Walk2D w = make_walk(strips * FAST_J, bh);
-        const int x = xb + w.c0;
-        if (x >= 0 && x < g.aw)
-            for (int r = w.r0; r < bh; r += w.rstep) {
-                const int y = yb + r;
+        const int bx0 = max(xb, 0), bx1 = min(xb + strips * FAST_J, g.aw);      // the block's columns inside the area
+        int nx, ny, cx0, cy0, step;
+        if (!scores && g.stride > 1 && g.masked && !ba.border) {
+            // the whole block lies in the interior: only the lattice from (xl0, yl0) is ever visited
+            // (matching.cpp:64-73); the -1 of the other cells is accounted for by the caller
+            step = g.stride;
+            const int i0 = small_div(bx0 - g.xl0 + step - 1, step), i1 = small_div(bx1 - 1 - g.xl0, step);
+            const int j0 = small_div(yb - g.yl0 + step - 1, step), j1 = small_div(yb + bh - 1 - g.yl0, step);
+            nx = i1 - i0 + 1; ny = j1 - j0 + 1;
+            cx0 = g.xl0 + i0 * step; cy0 = g.yl0 + j0 * step;
+        } else {
+            step = 1; nx = bx1 - bx0; ny = bh; cx0 = bx0; cy0 = yb;
+        }
+        if (nx > 0 && ny > 0) {
+            const float rnx = __builtin_amdgcn_rcpf((float)nx);
+            for (int i = lane; i < nx * ny; i += SLAM_WG) {
+                const int r = (int)(((float)i + 0.5f) * rnx), c = i - r * nx;
+                const int x = cx0 + c * step, y = cy0 + r * step;
                 const float sc = cell_from_acc(g, acc, ba, big, x, y, nm);
                 const int idx = y * g.aw + x;
                 if (scores) scores[idx] = sc;
                 best_update(best, sc, idx);
             }
+        }
     }
     STAMP(14);
+}
+
+// First cell (row-major) the reference's loops never visit, as an argmax candidate with the score
+// map's initial value -1 (matching.cpp:53); idx == INT_MAX when every cell is visited.  Cold path.
+__device__ __noinline__ Best first_unvisited(Geo g) {
+    Best b = {-FLT_MAX, INT_MAX};
+    const int n = g.aw * g.ah;
+    for (int base = 0; base < n && b.idx == INT_MAX; base += SLAM_WG) {
+        const int i = base + (int)threadIdx.x;
+        Best c = {-FLT_MAX, INT_MAX};
+        if (i < n) {
+            const int y = i / g.aw, x = i - y * g.aw;
+            if (classify_cell(g, x, y) == CELL_NONE) { c.v = -1.f; c.idx = i; }
+        }
+        b = best_wave(c);
+    }
+    return b;
 }
 
 // True when the tiled core can run this job with the LDS it was given: the template must be at most
@@ -386,6 +420,9 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         if (!refine) {
             if (yb >= g.ah) {                              // scan finished: the argmax is known
                 best = best_wave(best);
+                // Visited cells score >= 0 or NaN.  If none scored, the maximum is the -1 of the first
+                // cell the reference never visits; lattice-only blocks skipped those, so look it up.
+                if (!scores && g.stride > 1 && g.masked && !(best.v >= 0.f)) best = first_unvisited(g);
                 if (nblocks == 1) { fs.valid = true; break; }
                 if (best.idx == INT_MAX || !(refine_always || (double)best.v < refine_below)) break;
                 // multi-block map: recompute the 3x3 cells around the peak into the accumulators

@@ -36,6 +36,10 @@ def _check_match(ctx, oracle, im, patch, pm, area, am, stride, exact=False):
     assert _same_float(got["response"], ref["response"])
     assert _same_float(got["dx"], ref["dx"]) and _same_float(got["dy"], ref["dy"])
     assert abs(got["dx"]) <= 0.5 and abs(got["dy"]) <= 0.5
+    # the same job without a score map (the search then evaluates only the cells the reference visits)
+    g2 = api.match_feature_in_area(ctx, im, patch, pm, area, am, stride, exact)
+    assert (g2["x"], g2["y"]) == (ref["x"], ref["y"]) and _same_float(g2["response"], ref["response"])
+    assert _same_float(g2["dx"], ref["dx"]) and _same_float(g2["dy"], ref["dy"])
     return ref, got
 
 
@@ -143,6 +147,13 @@ def test_match_edge_cases(ctx, oracle):
     ref, got = _check_match(ctx, oracle, z, patch, pm, (2, 2, 12, 12), None, 1)
     assert (got["x"], got["y"], got["response"]) == (1, 1, 0.0)      # all NaN -> (-1,-1)+area, max 0
     _check_match(ctx, oracle, z, patch, None, (2, 2, 12, 12), None, 1)
+    # with a stride the unvisited cells keep -1, which then beats the NaNs: first unvisited cell wins
+    ref, got = _check_match(ctx, oracle, z, patch, pm, (2, 2, 12, 12), None, 3)
+    assert got["response"] == -1.0
+    _check_match(ctx, oracle, z, patch, pm, (6, 6, 9, 9), None, 2)      # window fully interior: lattice-only blocks
+    zz = np.zeros((60, 60), np.uint8)
+    ref, got = _check_match(ctx, oracle, zz, patch, pm, (20, 20, 12, 12), None, 3)
+    assert got["response"] == -1.0 and (got["x"], got["y"]) == (21, 20)
     # patch larger than the image, 1x1 patch, 1x1 area, stride beyond the window
     big = rng.integers(0, 256, (50, 60), dtype=np.uint8)
     _check_match(ctx, oracle, im, big, None, (5, 5, 10, 10), None, 1)
