@@ -105,7 +105,7 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
         o.x = -1 + g.ax; o.y = -1 + g.ay; o.response = 0.f;
         return o;
     }
-    const int ly = b.idx / g.aw, lx = b.idx - ly * g.aw;
+    const int ly = row_of_idx(g, b.idx), lx = b.idx - ly * g.aw;
     o.x = lx + g.ax; o.y = ly + g.ay; o.response = b.v;
     if (!(refine_always || (double)b.v < refine_below)) return o;
 
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
         t.scale_x = lane_f64(scx_l, i); t.scale_y = lane_f64(scy_l, i);
         // feature.cpp:144-146
-        const int rx = (int)round((double)__fsub_rn(__fdiv_rn(tx, sub), searchRad));
-        const int ry = (int)round((double)__fsub_rn(__fdiv_rn(ty, sub), searchRad));
+        const int rx = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(tx, sub), searchRad)));
+        const int ry = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(ty, sub), searchRad)));
         const Geo g = make_geo(ld + (long long)job.frame * ls, lw, lh, lp, t.tw, t.th, rx, ry, rs, rs,
                                nullptr, (i == 0) ? 1 : job.stride, true, false);   // feature.cpp:147-149
         int mx = 0, my = 0;

@@ -89,6 +89,15 @@ __device__ __forceinline__ float score_mt_n(unsigned long long CC, unsigned long
 __device__ __forceinline__ unsigned rcp_u32(unsigned d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 __device__ __forceinline__ unsigned div_rcp(unsigned n, unsigned d, unsigned rcp) { return d == 1 ? n : __umulhi(n, rcp); }
 
+// floor(n / d) for 0 <= n < 2^20, d >= 1 through one v_rcp_f32 (1 ulp): (n + 0.5) / d is at least
+// 0.5/d away from an integer, far more than the float rounding error at these magnitudes.
+__device__ __forceinline__ int small_div(int n, int d) {
+    return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+}
+// the same for wave-uniform operands: the quotient goes back to a scalar register so that the
+// integer arithmetic that follows stays on the scalar unit
+__device__ __forceinline__ int small_div_u(int n, int d) { return __builtin_amdgcn_readfirstlane(small_div(n, d)); }
+
 // ---- geometry -------------------------------------------------------------------------------
 struct Geo {
     const uint8_t* im;        // level image of the job's frame
@@ -101,7 +110,7 @@ struct Geo {
     int x0, y0;               // image position of patch pixel (0,0) for cell (0,0) (matching.cpp:38-39)
     int xl0, xl1, yl0, yl1;   // cells whose whole patch is inside the image (matching.cpp:44-49)
     int stride;
-    unsigned sinv;            // ceil(2^32 / stride): n % stride without a division for n*stride < 2^32
+    float rstride;            // 1 / stride (v_rcp_f32): n % stride without an integer division
     int yf;                   // first multiple of stride >= yl0
     bool masked;              // patchMask given
     bool exact;               // useExactAreaMask
@@ -130,15 +139,21 @@ __device__ __forceinline__ Geo make_geo(const uint8_t* im, int w, int h, long lo
     const int y0ua = max(g.y0, 0), y1ua = min(h, g.y0 + g.ah + ph - 1);
     g.xl0 = x0ua - g.x0; g.xl1 = x1ua - g.x0 - pw + 1;
     g.yl0 = y0ua - g.y0; g.yl1 = y1ua - g.y0 - ph + 1;
-    g.yf = (g.yl0 + stride - 1) / stride * stride;
-    g.sinv = (unsigned)((0x100000000ull + (unsigned)stride - 1) / (unsigned)stride);
+    g.rstride = __builtin_amdgcn_rcpf((float)stride);
+    g.yf = (stride > (1 << 19)) ? ((g.yl0 + stride - 1) / stride * stride)
+                                : (int)(((float)(g.yl0 + stride - 1) + 0.5f) * g.rstride) * stride;
     return g;
 }
 
-// n % g.stride for 0 <= n < 2^20 (stride <= 1024 keeps n*stride < 2^32, where the reciprocal is exact)
+// n % g.stride for 0 <= n <= 2^20 (see small_div for the exactness of the float quotient)
 __device__ __forceinline__ int mod_stride(const Geo& g, int n) {
-    if (g.stride > 4096) return n % g.stride;
-    return n - (int)__umulhi((unsigned)n, g.sinv) * g.stride;
+    return n - (int)(((float)n + 0.5f) * g.rstride) * g.stride;
+}
+
+// row of the (wave-uniform) linear cell index idx = y*aw + x
+__device__ __forceinline__ int row_of_idx(const Geo& g, int idx) {
+    if ((long long)g.aw * g.ah <= (1 << 20)) return small_div_u(idx, g.aw);
+    return __builtin_amdgcn_readfirstlane(idx / g.aw);
 }
 
 enum CellKind { CELL_NONE = 0, CELL_F32_FULL = 1, CELL_MT = 2, CELL_F32_CROP = 3 };

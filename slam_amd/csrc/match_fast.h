@@ -127,12 +127,6 @@ struct Walk2D {
     int r0, c0, rstep, cstep;
 };
 
-// floor(n / d) for 0 <= n < 2^19, d >= 1 through one v_rcp_f32 (1 ulp): (n + 0.5) / d is at least
-// 0.5/d away from an integer, far more than the float rounding error at these magnitudes.
-__device__ __forceinline__ int small_div(int n, int d) {
-    return (int)(((float)n + 0.5f) * __builtin_amdgcn_rcpf((float)d));
-}
-
 __device__ __forceinline__ Walk2D make_walk(int width, int rows) {
     Walk2D w;
     const int lane = threadIdx.x;
@@ -162,7 +156,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
     lds_u32* tile = reinterpret_cast<lds_u32*>(lds + lp.acc_bytes + lp.tmpl_bytes);
     const int strips = ba.strips, bh = ba.bh, xb = ba.xb, yb = ba.yb;
     const int tp = (strips + G) | 1;                       // odd dword pitch: rows spread over the banks
-    const int trows_cap = small_div(lp.tile_bytes / 4 / (ba.border ? 2 : 1), tp);
+    const int trows_cap = small_div_u(lp.tile_bytes / 4 / (ba.border ? 2 : 1), tp);
     lds_u32* vtile = tile + trows_cap * tp;
     const int units = strips * bh;
     const int ntask = units * S;
@@ -321,8 +315,8 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
             // the whole block lies in the interior: only the lattice from (xl0, yl0) is ever visited
             // (matching.cpp:64-73); the -1 of the other cells is accounted for by the caller
             step = g.stride;
-            const int i0 = small_div(bx0 - g.xl0 + step - 1, step), i1 = small_div(bx1 - 1 - g.xl0, step);
-            const int j0 = small_div(yb - g.yl0 + step - 1, step), j1 = small_div(yb + bh - 1 - g.yl0, step);
+            const int i0 = small_div_u(bx0 - g.xl0 + step - 1, step), i1 = small_div_u(bx1 - 1 - g.xl0, step);
+            const int j0 = small_div_u(yb - g.yl0 + step - 1, step), j1 = small_div_u(yb + bh - 1 - g.yl0, step);
             nx = i1 - i0 + 1; ny = j1 - j0 + 1;
             cx0 = g.xl0 + i0 * step; cy0 = g.yl0 + j0 * step;
         } else {
@@ -403,9 +397,9 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
     // does any cell's patch leave the image?  Then blocks may need the validity tile and a third sum.
     const bool any_border = g.xl0 > 0 || g.yl0 > 0 || g.xl1 < g.aw || g.yl1 < g.ah;
     const int tp_max = (strips_max + G) | 1;
-    const int TR = max(1, small_div(lp.tile_bytes / 4 / (any_border ? 2 : 1), tp_max));
-    const int cap_rows = max(1, small_div(lp.acc_bytes / ((any_border ? 3 : 2) * (big ? 8 : 4)), BW));
-    int UR = max(1, min(min(g.ph, small_div(lp.tmpl_bytes / 8, G)), TR));
+    const int TR = max(1, small_div_u(lp.tile_bytes / 4 / (any_border ? 2 : 1), tp_max));
+    const int cap_rows = max(1, small_div_u(lp.acc_bytes / ((any_border ? 3 : 2) * (big ? 8 : 4)), BW));
+    int UR = max(1, min(min(g.ph, small_div_u(lp.tmpl_bytes / 8, G)), TR));
     int BH = min(g.ah, cap_rows);
     if (BH + UR - 1 > TR) {
         // prefer whole-template chunks: shrink the block first, then the chunk
@@ -420,13 +414,15 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         if (!refine) {
             if (yb >= g.ah) {                              // scan finished: the argmax is known
                 best = best_wave(best);
+                best.idx = __builtin_amdgcn_readfirstlane(best.idx);
+                best.v = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(best.v)));
                 // Visited cells score >= 0 or NaN.  If none scored, the maximum is the -1 of the first
                 // cell the reference never visits; lattice-only blocks skipped those, so look it up.
                 if (!scores && g.stride > 1 && g.masked && !(best.v >= 0.f)) best = first_unvisited(g);
                 if (nblocks == 1) { fs.valid = true; break; }
                 if (best.idx == INT_MAX || !(refine_always || (double)best.v < refine_below)) break;
                 // multi-block map: recompute the 3x3 cells around the peak into the accumulators
-                const int ly = best.idx / g.aw, lx = best.idx - ly * g.aw;
+                const int ly = row_of_idx(g, best.idx), lx = best.idx - ly * g.aw;
                 refine = true;
                 ba.xb = ((max(lx - 1, 0) + o) & ~3) - o;
                 ba.strips = ((min(lx + 1, g.aw - 1) - ba.xb) >> 2) + 1;
