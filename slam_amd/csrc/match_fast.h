@@ -248,6 +248,24 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         {
             const int trows = bh + ur - 1;
             const int iy0 = g.y0 + yb + u0;
+            if (aligned && !ba.border && ix0 >= 0 && ix0 + 4 * tp <= g.w && iy0 >= 0 && iy0 + trows <= g.h) {
+                // the whole tile lies inside the image: plain dword copies, four loads in flight per lane
+                const uint8_t* base = g.im + (long long)iy0 * g.ipitch + ix0;
+                const int n = trows * tp;
+                const float rtp = __builtin_amdgcn_rcpf((float)tp);
+                for (int i0 = lane; i0 < n; i0 += 4 * SLAM_WG) {
+                    unsigned v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = min(i0 + q * SLAM_WG, n - 1);
+                        const int r = (int)(((float)i + 0.5f) * rtp), c = i - r * tp;
+                        v[q] = *reinterpret_cast<const unsigned*>(base + (long long)r * g.ipitch + 4 * c);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (i0 + q * SLAM_WG < n) tile[i0 + q * SLAM_WG] = v[q];
+                }
+            } else {
             const Walk2D w = make_walk(tp, trows);
             for (int r = w.r0; r < trows; r += w.rstep) {
                 const int iy = iy0 + r;
@@ -271,6 +289,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
                     tile[r * tp + c] = px;
                     if (ba.border) vtile[r * tp + c] = vv;
                 }
+            }
             }
         }
         __syncthreads();
