@@ -98,9 +98,17 @@ __device__ __forceinline__ unsigned long long acc_read(const lds_u8* acc, int i,
 
 // Score-map value of block cell (x,y) from the block's accumulators (-1 for cells the reference
 // never visits).  One sqrt(double) of the window energy serves all three formulas.
+// `on_lattice`: the caller enumerates only cells of the interior lattice of a block without border
+// cells, so the lattice and border tests of classify_cell are already decided.
 __device__ __forceinline__ float cell_from_acc(const Geo& g, const lds_u8* acc, const BlockArgs& ba, bool big,
-                                               int x, int y, const Norms& nm) {
-    const int kind = classify_cell(g, x, y);
+                                               int x, int y, const Norms& nm, bool on_lattice = false) {
+    int kind;
+    if (on_lattice) {
+        const bool am = !g.amask || g.amask[(long long)y * g.ampitch + x] != 0;
+        kind = g.masked ? (am ? CELL_F32_FULL : CELL_NONE) : ((g.exact && !am) ? CELL_NONE : CELL_MT);
+    } else {
+        kind = classify_cell(g, x, y);
+    }
     if (kind == CELL_NONE) return -1.f;                    // matching.cpp:53
     const int aw = ba.border ? 3 : 2;
     const int c = ((y - ba.yb) * ba.strips) * FAST_J + (x - ba.xb);      // (row*strips + strip)*4 + k
@@ -156,7 +164,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
     lds_u32* tile = reinterpret_cast<lds_u32*>(lds + lp.acc_bytes + lp.tmpl_bytes);
     const int strips = ba.strips, bh = ba.bh, xb = ba.xb, yb = ba.yb;
     const int tp = (strips + G) | 1;                       // odd dword pitch: rows spread over the banks
-    const int trows_cap = small_div_u(lp.tile_bytes / 4 / (ba.border ? 2 : 1), tp);
+    const int trows_cap = small_div_u((lp.tile_bytes >> 2) >> (ba.border ? 1 : 0), tp);
     lds_u32* vtile = tile + trows_cap * tp;
     const int units = strips * bh;
     const int ntask = units * S;
@@ -330,6 +338,9 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
     if (update) {
         const int bx0 = max(xb, 0), bx1 = min(xb + strips * FAST_J, g.aw);      // the block's columns inside the area
         int nx, ny, cx0, cy0, step;
+        // in a block without border cells every enumerated cell is decided without classify_cell:
+        // all cells for stride 1 or no patch mask (matching.cpp:151-153), else the interior lattice
+        const bool decided = !ba.border && (g.stride == 1 || !g.masked || !scores);
         if (!scores && g.stride > 1 && g.masked && !ba.border) {
             // the whole block lies in the interior: only the lattice from (xl0, yl0) is ever visited
             // (matching.cpp:64-73); the -1 of the other cells is accounted for by the caller
@@ -346,7 +357,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
             for (int i = lane; i < nx * ny; i += SLAM_WG) {
                 const int r = (int)(((float)i + 0.5f) * rnx), c = i - r * nx;
                 const int x = cx0 + c * step, y = cy0 + r * step;
-                const float sc = cell_from_acc(g, acc, ba, big, x, y, nm);
+                const float sc = cell_from_acc(g, acc, ba, big, x, y, nm, decided);
                 const int idx = y * g.aw + x;
                 if (scores) scores[idx] = sc;
                 best_update(best, sc, idx);
@@ -416,8 +427,8 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
     // does any cell's patch leave the image?  Then blocks may need the validity tile and a third sum.
     const bool any_border = g.xl0 > 0 || g.yl0 > 0 || g.xl1 < g.aw || g.yl1 < g.ah;
     const int tp_max = (strips_max + G) | 1;
-    const int TR = max(1, small_div_u(lp.tile_bytes / 4 / (any_border ? 2 : 1), tp_max));
-    const int cap_rows = max(1, small_div_u(lp.acc_bytes / ((any_border ? 3 : 2) * (big ? 8 : 4)), BW));
+    const int TR = max(1, small_div_u((lp.tile_bytes >> 2) >> (any_border ? 1 : 0), tp_max));
+    const int cap_rows = max(1, small_div_u(small_div_u(lp.acc_bytes >> (big ? 3 : 2), any_border ? 3 : 2), BW));
     int UR = max(1, min(min(g.ph, small_div_u(lp.tmpl_bytes / 8, G)), TR));
     int BH = min(g.ah, cap_rows);
     if (BH + UR - 1 > TR) {
