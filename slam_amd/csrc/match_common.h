@@ -288,14 +288,29 @@ __device__ __forceinline__ Sums cell_sums_partial(const Geo& g, const Tmpl& t, i
     return s;
 }
 
+// Inclusive scan step helpers on the 64 lanes with DPP moves (no LDS traffic): four row_shr steps
+// inside each row of 16 lanes, then row_bcast:15 and row_bcast:31 carry the row totals upwards; lane
+// 63 ends up with the reduction over all lanes.  Lanes without a source keep `identity`.
+#define SLAM_DPP_ROW_SHR(n) (0x110 + (n))
+#define SLAM_DPP_BCAST15 0x142
+#define SLAM_DPP_BCAST31 0x143
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_BCAST15, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_BCAST31, 0xc, 0xf, false);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Sum over the wavefront of per-lane values below 2^48 (three 16-bit digits: each digit sum stays
+// below 2^22); the result is wave-uniform.
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)v, o, 64);
-        const unsigned hi = __shfl_xor((unsigned)(v >> 32), o, 64);
-        v += ((unsigned long long)hi << 32) | lo;
-    }
-    return v;
+    const unsigned d0 = (unsigned)v & 0xffffu, d1 = (unsigned)(v >> 16) & 0xffffu, d2 = (unsigned)(v >> 32) & 0xffffu;
+    return (unsigned long long)wave_sum_u32(d0) + ((unsigned long long)wave_sum_u32(d1) << 16) +
+           ((unsigned long long)wave_sum_u32(d2) << 32);
 }
 
 // ---- argmax ---------------------------------------------------------------------------------
@@ -307,14 +322,40 @@ __device__ __forceinline__ void best_update(Best& b, float v, int idx) {
     if (v > b.v || (v == b.v && idx < b.idx)) { b.v = v; b.idx = idx; }
 }
 
+// Wave-wide argmax, wave-uniform result.  (score, index) is ordered as one 64-bit key: the score's
+// bits made monotonic in the high word, the inverted index in the low word, so the maximum key is
+// the largest score and, among equal scores, the smallest index.  Scores are never NaN here
+// (best_update does not store them); lanes that saw nothing hold (-FLT_MAX, INT_MAX).
 __device__ __forceinline__ Best best_wave(Best b) {
+    const unsigned fb = (unsigned)__float_as_int(b.v);
+    unsigned hi = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+    unsigned lo = ~(unsigned)b.idx;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const float ov = __shfl_xor(b.v, o, 64);
-        const int oi = __shfl_xor(b.idx, o, 64);
-        if (ov > b.v || (ov == b.v && oi < b.idx)) { b.v = ov; b.idx = oi; }
+    for (int step = 0; step < 6; step++) {
+        unsigned oh, ol;
+        switch (step) {
+            case 0: oh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, SLAM_DPP_ROW_SHR(1), 0xf, 0xf, false);
+                    ol = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, SLAM_DPP_ROW_SHR(1), 0xf, 0xf, false); break;
+            case 1: oh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, SLAM_DPP_ROW_SHR(2), 0xf, 0xf, false);
+                    ol = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, SLAM_DPP_ROW_SHR(2), 0xf, 0xf, false); break;
+            case 2: oh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, SLAM_DPP_ROW_SHR(4), 0xf, 0xf, false);
+                    ol = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, SLAM_DPP_ROW_SHR(4), 0xf, 0xf, false); break;
+            case 3: oh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, SLAM_DPP_ROW_SHR(8), 0xf, 0xf, false);
+                    ol = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, SLAM_DPP_ROW_SHR(8), 0xf, 0xf, false); break;
+            case 4: oh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, SLAM_DPP_BCAST15, 0xa, 0xf, false);
+                    ol = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, SLAM_DPP_BCAST15, 0xa, 0xf, false); break;
+            default: oh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, SLAM_DPP_BCAST31, 0xc, 0xf, false);
+                     ol = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, SLAM_DPP_BCAST31, 0xc, 0xf, false); break;
+        }
+        const bool take = oh > hi || (oh == hi && ol > lo);      // key 0 (no source lane) never wins
+        hi = take ? oh : hi; lo = take ? ol : lo;
     }
-    return b;
+    hi = (unsigned)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+    Best r;
+    r.v = __int_as_float((int)((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi));
+    r.idx = (int)~lo;
+    return r;
 }
 
 }  // namespace slamdev
