@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat the CPU sample until this much CPU time")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--rehearse-one-device", action="store_true",
+                    help="diagnostic: every rank uses cuda:0 (rehearsal of the N > 1 control flow on a one-GPU box, with --backend gloo)")
     ap.add_argument("--with-h2d", action="store_true",
                     help="diagnostic: each step also uploads the frames from pinned host memory (PCIe-inclusive rate)")
     args = ap.parse_args()
@@ -156,11 +159,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if args.rehearse_one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rdev = dev if args.backend == "nccl" else torch.device("cpu")     # where the two reduced scalars live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     rng = np.random.default_rng(0x51A40002 + 7919 * rank)
     frames, jobs, blob, truth = build_workload(args.frames, 0x51A40002 + 1000 * rank, rng)
@@ -244,7 +253,7 @@ def main():
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     tot_pos = float(positions)
-    elapsed, tot_pos = parallel.reduce_max_sum(elapsed, tot_pos, dev)
+    elapsed, tot_pos = parallel.reduce_max_sum(elapsed, tot_pos, rdev)
 
     if rank == 0:
         traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
