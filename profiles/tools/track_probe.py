@@ -51,6 +51,9 @@ def run(subs, tsize, nframes=512, steps=10, thr=0.98, stride=3, mask_cut=True):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "one":      # one configuration that never stops early (for counter passes)
+        run([1.0, 2.0, 4.0], 21, nframes=1024, steps=2, thr=-10.0)
+        sys.exit(0)
     run([1.0, 2.0, 4.0], 21)
     run([1.0, 2.0, 4.0], 21, thr=0.0)      # never stops early
     run([1.0], 21)

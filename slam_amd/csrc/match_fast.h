@@ -303,6 +303,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         __syncthreads();
         STAMP(12);
         // ---- accumulate: the lanes walk the (strip, row-slice) tasks -----------------------------
+#ifndef DIAG_SKIP_ACC
         for (int task = lane; task < ntask; task += SLAM_WG) {
             const int unit = small_div(task, S), slice = task - unit * S;
             const int row = small_div(unit, strips), strip = unit - row * strips;
@@ -326,6 +327,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
                 }
             }
         }
+#endif
     }
     STAMP(13);
     if (first_block) {                                     // |patch0|^2 over the whole template
@@ -335,6 +337,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
     __syncthreads();
 
     // ---- scores of the block's cells, running argmax ---------------------------------------------
+#ifndef DIAG_SKIP_FIN
     if (update) {
         const int bx0 = max(xb, 0), bx1 = min(xb + strips * FAST_J, g.aw);      // the block's columns inside the area
         int nx, ny, cx0, cy0, step;
@@ -364,6 +367,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
             }
         }
     }
+#endif
     STAMP(14);
 }
 
