@@ -23,6 +23,7 @@ constexpr int FAST_WG = 256;
 constexpr int FAST_CHUNK = 256;                 // pixels per chunk: 4 per lane
 constexpr int FAST_PPITCH = FAST_CHUNK + 8;     // pixel tile pitch: 4 halo columns each side
 constexpr int FAST_LDS_BUDGET = 40 * 1024;
+constexpr int FAST_CL_CAP = 1024;               // corners a band can list for the sparse non-max pass
 
 struct FastPlan {
     int R;            // rows per band; R + 2 score rows are a multiple of 4 (one share per wavefront)
@@ -34,9 +35,10 @@ struct FastPlan {
 __host__ __device__ inline size_t fast_lds_bytes(int R, int spitch) {
     // score tile + pixel chunk + candidate lists (4 wavefronts x up to 8 rows x 256 slots x 2 bytes);
     // phase 3 reuses the pixel chunk + lists as one keep-flag byte per 4 pixels (R * spitch / 4 bytes)
+    // a list of the band's corners (FAST_CL_CAP dwords) follows
     const size_t work = (size_t)(R + 8) * FAST_PPITCH + 4 * 8 * 256 * 2;
     const size_t flags = (size_t)R * (spitch / 4);
-    return (size_t)(R + 2) * spitch + (work > flags ? work : flags);
+    return (size_t)(R + 2) * spitch + ((work > flags ? work : flags) + 15) / 16 * 16 + 16 + (size_t)FAST_CL_CAP * 4;
 }
 
 bool fast_plan(int w, int h, FastPlan& p) {
@@ -102,6 +104,18 @@ __device__ __forceinline__ void fast_arc_scores(const fl_u8* p, int pitch, int& 
     a_dark = best.x; a_bright = best.y;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP moves: four row_shr steps inside each row of 16
+// lanes, then row_bcast:15 / row_bcast:31 carry the row totals upwards.
+__device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     const uint8_t* __restrict__ frames, int w, int h, long long pitch, long long frame_stride,
     int threshold, int nonmax, int R, int spitch, int nbands, int cap, unsigned* __restrict__ scratch) {
@@ -111,6 +125,9 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     fl_u8* sc = (fl_u8*)smem;                                    // (R+2) x spitch stored scores; column x at byte x + 4
     fl_u8* px = sc + (size_t)(R + 2) * spitch;                   // (R+8) x FAST_PPITCH pixels of the current chunk
     fl_u16* lists = (fl_u16*)(px + (size_t)(R + 8) * FAST_PPITCH);   // 4 x (8 rows x 256) candidate slots
+    const size_t work_bytes = (size_t)(R + 8) * FAST_PPITCH + 4 * 8 * 256 * 2, flag_bytes = (size_t)R * (spitch / 4);
+    fl_u32* ccount = (fl_u32*)(px + ((work_bytes > flag_bytes ? work_bytes : flag_bytes) + 15) / 16 * 16);
+    fl_u32* clist = ccount + 4;                                   // corners of band rows: (band row << 16) | column
 
     const int band = blockIdx.x, frame = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     const bool aligned = ((reinterpret_cast<unsigned long long>(frames) | (unsigned long long)pitch | (unsigned long long)frame_stride) & 3ull) == 0;
     const int t = threshold;
 
+    if (tid == 0) *ccount = 0u;
     {   // zero the score tile
         fl_u32* z = (fl_u32*)sc;
         const int n = ((R + 2) * spitch) >> 2;
@@ -223,7 +241,13 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
             int ad, ab;
             fast_arc_scores(px + (ry + 3) * FAST_PPITCH + 4 + lx, FAST_PPITCH, ad, ab);
             const int a = max(ad, ab);
-            if (a > t) sc[ry * spitch + 4 + cx + lx] = (unsigned char)(nonmax ? a - 1 : a);   // no NMS: score + 1 marks a corner
+            if (a > t) {
+                sc[ry * spitch + 4 + cx + lx] = (unsigned char)(nonmax ? a - 1 : a);   // no NMS: score + 1 marks a corner
+                if (ry >= 1 && ry <= R) {                        // halo rows only serve as neighbours
+                    const unsigned pos = __hip_atomic_fetch_add(ccount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pos < (unsigned)FAST_CL_CAP) clist[pos] = ((unsigned)(ry - 1) << 16) | (unsigned)(cx + lx);
+                }
+            }
         }
     }
     __syncthreads();
@@ -231,6 +255,69 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     // ---- phase 3: non-max suppression and ordered compaction; pass 0 counts, pass 1 writes
     const int r_lo = (R * wid) >> 2, r_hi = (R * (wid + 1)) >> 2;   // this wavefront's band rows
     unsigned* pool = fs + 4 + 2 * ((nbands + 3) / 4 * 4);
+    const int ncorner = (int)*ccount;
+    const int wpr = (w + 31) >> 5;                               // bitmap words per row
+    if (ncorner <= FAST_CL_CAP && (size_t)R * wpr * 4 <= work_bytes) {
+        // Sparse band: one lane per listed corner decides the non-max test and sets its bit in a
+        // band bitmap (over the pixel chunk, free now); the bitmap is then read out in row-major order.
+        fl_u32* bmp = (fl_u32*)px;
+        for (int i = tid; i < R * wpr; i += FAST_WG) bmp[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < ncorner; i += FAST_WG) {
+            const unsigned e = clist[i];
+            const int ry = (int)(e >> 16), x = (int)(e & 0xffffu);
+            const int y = y0 + ry;
+            if (y < 3 || y >= h - 3) continue;
+            const fl_u8* c = sc + (ry + 1) * spitch + 4 + x;
+            bool keep = true;
+            if (nonmax) {
+                const int s0 = c[0];
+                int nb = max(max((int)c[-1], (int)c[1]), max((int)c[-spitch], (int)c[spitch]));
+                nb = max(nb, max(max((int)c[-spitch - 1], (int)c[-spitch + 1]), max((int)c[spitch - 1], (int)c[spitch + 1])));
+                keep = s0 > nb;
+            }
+            if (keep) __hip_atomic_fetch_or(bmp + ry * wpr + (x >> 5), 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        int cnt = 0;
+        for (int ry = r_lo; ry < r_hi; ry++)
+            for (int wb = 0; wb < wpr; wb += 64)
+                if (wb + lane < wpr) cnt += __popc(bmp[ry * wpr + wb + lane]);
+        {
+            const unsigned tot = wave_scan_incl((unsigned)cnt);
+            if (lane == 63) wave_cnt[wid] = (int)tot;
+        }
+        __syncthreads();
+        const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
+        const int total = c0 + c1 + c2 + c3;
+        if (tid == 0) {
+            int off = 0;
+            if (total > 0) off = (int)atomicAdd(&fs[0], (unsigned)total);
+            pool_off = off;
+            const int nb4 = (nbands + 3) / 4 * 4;
+            fs[4 + band] = (unsigned)off;
+            fs[4 + nb4 + band] = (unsigned)total;
+        }
+        __syncthreads();
+        if (total == 0) return;
+        int pos0 = pool_off + ((wid == 0) ? 0 : (wid == 1) ? c0 : (wid == 2) ? c0 + c1 : c0 + c1 + c2);
+        for (int ry = r_lo; ry < r_hi; ry++)
+            for (int wb = 0; wb < wpr; wb += 64) {
+                unsigned m = (wb + lane < wpr) ? bmp[ry * wpr + wb + lane] : 0u;
+                const unsigned incl = wave_scan_incl((unsigned)__popc(m));
+                int pos = pos0 + (int)incl - __popc(m);
+                pos0 += (int)__builtin_amdgcn_readlane((int)incl, 63);
+                while (m) {
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1u;
+                    const int x = ((wb + lane) << 5) + b;
+                    const unsigned s = sc[(ry + 1) * spitch + 4 + x];
+                    if (pos < cap) pool[pos] = ((unsigned)(ry * w + x) << 8) | (nonmax ? s : s - 1u);
+                    pos++;
+                }
+            }
+        return;
+    }
     fl_u8* flags = px;                                           // the pixel chunk and the lists are free now
     const int fpitch = spitch >> 2;
     int base = 0;
@@ -326,34 +413,39 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     }
 }
 
+// One workgroup per (band, frame): finds the band's place in the frame's output by summing the
+// counts of the bands before it, then converts and copies its keys.
 __global__ __launch_bounds__(FAST_WG) void fast_gather_kernel(int w, int R, int nbands, int cap,
                                                               const unsigned* __restrict__ scratch,
                                                               slam_keypoint* __restrict__ out,
                                                               int* __restrict__ counts) {
-    const int frame = blockIdx.x, tid = threadIdx.x;
+    __shared__ int part[4];
+    const int band = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
     const unsigned* fs = scratch + (size_t)frame * fast_frame_words(nbands, cap);
     const int nb4 = (nbands + 3) / 4 * 4;
     const unsigned* band_off = fs + 4;
     const unsigned* band_cnt = fs + 4 + nb4;
     const unsigned* pool = fs + 4 + 2 * nb4;
     slam_keypoint* o = out + (size_t)frame * cap;
-    int base = 0;   // every thread walks the bands; counts are tiny compared with the copies
-    for (int b = 0; b < nbands; b++) {
-        const int cnt = (int)band_cnt[b], off = (int)band_off[b];
-        for (int i = tid; i < cnt; i += FAST_WG) {
-            const int dst = base + i;
-            if (dst < cap && off + i < cap) {
-                const unsigned key = pool[off + i];
-                const unsigned lin = key >> 8;
-                const int ry = (int)(lin / (unsigned)w), x = (int)(lin - (unsigned)ry * (unsigned)w);
-                slam_keypoint kp;
-                kp.x = (float)x; kp.y = (float)(b * R + ry); kp.response = (float)(key & 0xffu);
-                o[dst] = kp;
-            }
+    unsigned mine = 0;
+    for (int b = tid; b < band; b += FAST_WG) mine += band_cnt[b];
+    const unsigned tot = wave_scan_incl(mine);
+    if ((tid & 63) == 63) part[tid >> 6] = (int)tot;
+    __syncthreads();
+    const int base = part[0] + part[1] + part[2] + part[3];
+    const int cnt = (int)band_cnt[band], off = (int)band_off[band];
+    for (int i = tid; i < cnt; i += FAST_WG) {
+        const int dst = base + i;
+        if (dst < cap && off + i < cap) {
+            const unsigned key = pool[off + i];
+            const unsigned lin = key >> 8;
+            const int ry = (int)(lin / (unsigned)w), x = (int)(lin - (unsigned)ry * (unsigned)w);
+            slam_keypoint kp;
+            kp.x = (float)x; kp.y = (float)(band * R + ry); kp.response = (float)(key & 0xffu);
+            o[dst] = kp;
         }
-        base += cnt;
     }
-    if (tid == 0) counts[frame] = base;
+    if (band == nbands - 1 && tid == 0) counts[frame] = base + cnt;
 }
 
 }  // namespace
@@ -388,7 +480,7 @@ extern "C" int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, in
                        d_frames, w, h, (long long)pitch, (long long)frame_stride, threshold, nonmax ? 1 : 0,
                        p.R, p.spitch, p.nbands, cap_per_frame, (unsigned*)d_scratch);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(fast_gather_kernel, dim3(nframes), dim3(FAST_WG), 0, ctx->stream, w, p.R, p.nbands,
+    hipLaunchKernelGGL(fast_gather_kernel, dim3(p.nbands, nframes), dim3(FAST_WG), 0, ctx->stream, w, p.R, p.nbands,
                        cap_per_frame, (const unsigned*)d_scratch, d_out, d_counts);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
