@@ -134,6 +134,32 @@ def oracle_run(frames, jobs, blob, nfr):
     return res, dt, pos
 
 
+def _oracle_worker(args):
+    """One process of the all-cores CPU baseline: tracks a slice of frames with the oracle."""
+    frames, jobs, blob = args
+    _, dt, pos = oracle_run(frames, jobs, blob, len(frames))
+    return dt, pos
+
+
+def oracle_run_parallel(frames, jobs, blob, nfr, nproc):
+    """The same oracle pass split over nproc worker processes (spawned: they never touch the GPU).
+    Returns (wall seconds of the parallel section, positions)."""
+    import multiprocessing as mp
+    parts = []
+    for k in range(nproc):
+        lo, hi = nfr * k // nproc, nfr * (k + 1) // nproc
+        if hi > lo:
+            jj = jobs[lo * NFEAT:hi * NFEAT].copy()
+            jj["frame"] -= lo
+            parts.append((frames[lo:hi], jj, blob))
+    with mp.get_context("spawn").Pool(len(parts)) as pool:
+        pool.map(_oracle_worker, [(p[0][:1], p[1][:NFEAT], p[2]) for p in parts])      # start-up and page-in, untimed
+        t0 = time.perf_counter()
+        res = pool.map(_oracle_worker, parts)
+        wall = time.perf_counter() - t0
+    return wall, sum(r[1] for r in res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +169,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat the CPU sample until this much CPU time")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=16,
+                    help="worker processes of the additional all-cores CPU figure (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--rehearse-one-device", action="store_true",
                     help="diagnostic: every rank uses cuda:0 (rehearsal of the N > 1 control flow on a one-GPU box, with --backend gloo)")
@@ -233,6 +261,10 @@ def main():
                "sample": "CPU oracle (pyramid + Feature::track) on the first %d frames x %d features of the same batch, "
                          "%d passes, single thread, %.1f s in all; results bit-identical to the GPU's"
                          % (nfr, NFEAT, passes, cpu_s)}
+        if args.cpu_procs > 1:     # secondary figure: the same port on the host cores this job may use
+            wall, pos = oracle_run_parallel(frames, jobs, blob, nfr, args.cpu_procs)
+            cpu["all_cores"] = {"value": pos / wall, "unit": "positions/s", "cores": args.cpu_procs,
+                                "sample": "same frames split over %d processes, %.1f s wall" % (args.cpu_procs, wall)}
 
     # ---- timing --------------------------------------------------------------------------------
     for _ in range(args.warmup):
