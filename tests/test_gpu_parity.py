@@ -388,3 +388,48 @@ def test_c4_full_batch_fast_properties(ctx, oracle):
         assert (neigh == 0).all()
     for i in (0, 37):
         assert np.array_equal(kps[i], oracle.fast(frames[i], thr, True))
+
+
+def test_c3_ellipse_windows_all_levels(ctx, oracle):
+    """C3 shape: 1280x720, pyramid {1,2,4,8}, 256 features with 31x31 masked templates; the coarsest
+    level is searched inside the bounding box of a random ellipse rasterised into an area mask
+    (patchMask + areaMask mode, matching.cpp:60-104), the finer levels in small masked windows.
+    Every job of the batch must equal the oracle's matchFeatureInArea on that level."""
+    w, h, subs = 1280, 720, [1.0, 2.0, 4.0, 8.0]
+    rng = np.random.default_rng(synth.SEED_BASE + 3)
+    frame = synth.frame(w, h, synth.SEED_BASE + 33)
+    pyr = api.ImagePyramid(ctx, frame, subs)
+    levels = oracle.pyramid(frame, subs)
+    try:
+        jobs, refs = [], []
+        for (cx, cy) in synth.feature_grid(w, h, 256, 40, rng):
+            lvl = int(rng.integers(0, 4))
+            sub = subs[lvl]
+            tsz = max(3, int(31 / sub))
+            im = levels[lvl]
+            lx, ly = int(cx / sub), int(cy / sub)
+            tx, ty = int(np.clip(lx, tsz // 2, im.shape[1] - tsz // 2 - 1)), int(np.clip(ly, tsz // 2, im.shape[0] - tsz // 2 - 1))
+            patch = synth.cut_template(im, tx, ty, tsz, tsz)
+            pm = np.ones_like(patch)
+            pm[0, :tsz // 3] = 0
+            pm[-1, -(tsz // 3):] = 0
+            if lvl == 3:
+                a, b, th = float(rng.uniform(24, 96)) / sub, float(rng.uniform(12, 48)) / sub, float(rng.uniform(0, np.pi))
+                ew = 2 * int(np.ceil(max(a, b))) + 1
+                area = (lx - ew // 2 + int(rng.integers(-2, 3)), ly - ew // 2 + int(rng.integers(-2, 3)), ew, ew)
+                am = synth.ellipse_mask(ew, ew, a, b, th)
+                stride = 1
+            else:
+                r = int(rng.integers(2, 9))
+                area = (lx - r + int(rng.integers(-3, 4)), ly - r, 2 * r + 1, 2 * r + 1)
+                am = None
+                stride = 1 if lvl == 0 else 3
+            jobs.append(dict(frame=0, level=lvl, patch=patch, patch_mask=pm, area=area, area_mask=am, stride=stride))
+            refs.append(oracle.match(im, patch, pm, area, am, stride))
+        got = api.match_batch(ctx, pyr, jobs)
+        for g, r in zip(got, refs):
+            assert g["status"] == 0
+            assert (g["x"], g["y"]) == (r["x"], r["y"])
+            assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+    finally:
+        pyr.close()
