@@ -201,6 +201,49 @@ int slam_hip_get_sorted_keypoints(slam_ctx* ctx, const uint8_t* im, int w, int h
                                   slam_keypoint* out, int cap, int32_t* n_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * New features — the steps that follow corner detection in SLAM::addNewLines (SLAM.hpp, new_point.cpp:
+ * 129-156): sort by response (new_point.cpp:124), greedy minimum-distance selection (new_point.cpp:
+ * 137-155) and the descriptor crop of the kept points (feature.cpp:42-45, lineFeature.cpp:7-10).
+ * ------------------------------------------------------------------------------------------- */
+/* Per-frame sort of slam_hip_fast_detect_d's output (row-major order) into d_out (same layout, must
+ * not alias d_in): response descending, ties by y then x ascending.  Asynchronous. */
+int slam_hip_sort_keypoints_d(slam_ctx* ctx, const slam_keypoint* d_in, const int32_t* d_counts,
+                              int nframes, int cap_per_frame, slam_keypoint* d_out);
+/* new_point.cpp:137-155 per frame on sorted keypoints.  Occupied positions (matches, then
+ * lineMatches) are xy float pairs, frame f owning pairs [d_occ_off[f], d_occ_off[f+1]) (both
+ * pointers may be NULL: nothing occupied).  d_sel receives nframes x n_new indices into the frame's
+ * sorted list, d_nsel the number kept per frame.  Asynchronous, allocates nothing. */
+int slam_hip_select_new_points_d(slam_ctx* ctx, const slam_keypoint* d_sorted, const int32_t* d_counts,
+                                 int nframes, int cap_per_frame, const float* d_occ_xy,
+                                 const int32_t* d_occ_off, int n_new, float min_dist, int rx, int ry,
+                                 int w, int h, int32_t* d_sel, int32_t* d_nsel);
+
+typedef struct slam_desc_job {
+    int32_t frame;
+    float   px, py;         /* pt2d */
+    int32_t rx, ry;         /* descriptor half sizes: (2ry+1) x (2rx+1) when not cropped by the border */
+    int32_t reserved;
+    int64_t out_off;        /* byte offset of the crop in the output buffer (rows packed) */
+} slam_desc_job;
+
+typedef struct slam_desc_result {
+    int32_t x0, y0, w, h;   /* the crop: rows [max(0,iround(y-ry)), min(H,iround(y+ry+1))), columns likewise */
+    int32_t status;
+} slam_desc_result;
+
+int slam_hip_extract_descriptors_d(slam_ctx* ctx, const uint8_t* d_frames, int w, int h, size_t pitch,
+                                   size_t frame_stride, int nframes, const slam_desc_job* d_jobs, int njobs,
+                                   uint8_t* d_out, size_t out_bytes, slam_desc_result* d_res);
+/* One frame, host tables: kps in cv::FAST order (already_sorted = 0) or sorted; sel / nsel as above;
+ * sorted_out (optional, nkps entries) receives the sorted list; descr_out (optional, n_new crops of
+ * (2rx+1)*(2ry+1) bytes) and descr_res the descriptors of the kept points. */
+int slam_hip_add_new_points(slam_ctx* ctx, const uint8_t* im, int w, int h, size_t pitch,
+                            const slam_keypoint* kps, int nkps, int already_sorted,
+                            const float* occ_xy, int nocc, int n_new, float min_dist, int rx, int ry,
+                            int32_t* sel, int32_t* nsel, slam_keypoint* sorted_out,
+                            uint8_t* descr_out, size_t descr_bytes, slam_desc_result* descr_res);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (used by the parity tests; no reference counterpart).
  * ------------------------------------------------------------------------------------------- */
 /* Evaluates the two score formulas of matching.cpp on the device for n triples of exact integer

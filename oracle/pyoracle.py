@@ -81,6 +81,14 @@ def lib():
         L.so_get_sorted_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_size_t,
                                               C.POINTER(C.c_float), C.POINTER(KeyPoint), C.c_int]
         L.so_get_sorted_keypoints.restype = C.c_int
+        L.so_sort_keypoints.argtypes = [C.c_void_p, C.c_int]
+        L.so_sort_keypoints.restype = None
+        L.so_select_new_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p]
+        L.so_select_new_points.restype = C.c_int
+        L.so_extract_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_float, C.c_float, C.c_int, C.c_int,
+                                            C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        L.so_extract_descriptor.restype = C.c_int
         L.so_proptest_srand.argtypes = [C.c_uint]
         L.so_proptest_srand.restype = None
         L.so_proptest_next.argtypes = [C.c_int, C.c_int, C.POINTER(PropCase)]
@@ -214,6 +222,34 @@ def get_sorted_keypoints(im, n_min_pts, fast_threshold):
     if n < 0:
         raise MemoryError
     return _kps(buf, min(n, cap)), f.value
+
+
+def sort_keypoints(kps):
+    """kps[n,3] (x, y, response) -> sorted by response desc, y asc, x asc (new_point.cpp:124)."""
+    a = np.ascontiguousarray(kps, dtype=np.float32).copy()
+    lib().so_sort_keypoints(a.ctypes.data, len(a))
+    return a
+
+
+def select_new_points(kps, occupied, n, min_dist, rx, ry, w, h):
+    """new_point.cpp:137-155 on sorted kps[n,3]; occupied[m,2] = positions of matches and lineMatches.
+    Returns the indices of the kept keypoints."""
+    a = np.ascontiguousarray(kps, dtype=np.float32)
+    occ = np.ascontiguousarray(occupied, dtype=np.float32).reshape(-1, 2)
+    sel = np.zeros(max(n, 1), np.int32)
+    k = lib().so_select_new_points(a.ctypes.data, len(a), occ.ctypes.data, len(occ), n, min_dist, rx, ry, w, h, sel.ctypes.data)
+    return sel[:k].copy()
+
+
+def extract_descriptor(im, px, py, rx, ry):
+    """feature.cpp:42-45: returns (crop array, (x0, y0, w, h))."""
+    im = _u8(im)
+    out = np.zeros((2 * ry + 2) * (2 * rx + 2), np.uint8)
+    r = [C.c_int() for _ in range(4)]
+    lib().so_extract_descriptor(im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], px, py, rx, ry, out.ctypes.data,
+                                *[C.byref(v) for v in r])
+    x0, y0, w, h = [v.value for v in r]
+    return out[:w * h].reshape(h, w).copy(), (x0, y0, w, h)
 
 
 class PropTest:

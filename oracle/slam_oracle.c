@@ -490,6 +490,50 @@ int so_get_sorted_keypoints(const uint8_t* im, int w, int h, ptrdiff_t pitch, si
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* new_point.cpp:129-156 (selection loop of addNewLines), feature.cpp:36-51 (descriptor crop)  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* cv::norm(Point2f a - Point2f b): the difference is formed in float, the norm in double. */
+static double pt_dist(float ax, float ay, float bx, float by) {
+    const float dx = ax - bx, dy = ay - by;
+    return sqrt((double)dx * dx + (double)dy * dy);
+}
+
+void so_sort_keypoints(so_keypoint* kps, int n) { qsort(kps, (size_t)n, sizeof(so_keypoint), kp_cmp); }
+
+int so_select_new_points(const so_keypoint* kps, int nkps, const float* occ_xy, int nocc, int n,
+                         float min_dist, int rx, int ry, int w, int h, int* sel) {
+    int nsel = 0;
+    for (int i = 0; i < nkps && n > 0; i++) {                 /* new_point.cpp:137 */
+        const float px = kps[i].x, py = kps[i].y;
+        int bad = 0;
+        for (int j = 0; j < nocc && !bad; j++)                /* new_point.cpp:139-144: matches, then lineMatches */
+            if (pt_dist(occ_xy[2 * j], occ_xy[2 * j + 1], px, py) < min_dist) bad = 1;
+        for (int j = 0; j < nsel && !bad; j++)                /* new_point.cpp:145-147 */
+            if (pt_dist(kps[sel[j]].x, kps[sel[j]].y, px, py) < min_dist) bad = 1;
+        if (!bad && ((py - ry < 0) || (px - rx < 0) || (py + ry >= h) || (px + rx >= w))) bad = 1;   /* :148-150 */
+        if (bad) continue;
+        sel[nsel++] = i;                                      /* new_point.cpp:151-153 */
+        --n;
+    }
+    return nsel;
+}
+
+static int iround_f(float a) { return (int)round((double)a); }   /* common.hpp:62-66 */
+
+int so_extract_descriptor(const uint8_t* im, int w, int h, ptrdiff_t pitch, float px, float py, int rx, int ry,
+                          uint8_t* out, int* ox, int* oy, int* ow, int* oh) {
+    /* feature.cpp:42-45 (and lineFeature.cpp:7-10): im(Range(max(0, iround(y-ry)), min(h, iround(y+ry+1))), Range(...x...)) */
+    const int y0 = imax(0, iround_f(py - (float)ry)), y1 = imin(h, iround_f(py + (float)ry + 1.f));
+    const int x0 = imax(0, iround_f(px - (float)rx)), x1 = imin(w, iround_f(px + (float)rx + 1.f));
+    *ox = x0; *oy = y0; *ow = x1 > x0 ? x1 - x0 : 0; *oh = y1 > y0 ? y1 - y0 : 0;
+    if (*ow == 0 || *oh == 0) { *ox = 0; *oy = 0; *ow = 0; *oh = 0; return 0; }
+    if (out)
+        for (int y = y0; y < y1; y++) memcpy(out + (size_t)(y - y0) * (size_t)(x1 - x0), im + (ptrdiff_t)y * pitch + x0, (size_t)(x1 - x0));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* tests/test_matching.cpp:13-101 restated                                                    */
 /* ------------------------------------------------------------------------------------------ */
 

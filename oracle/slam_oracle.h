@@ -99,6 +99,21 @@ int so_fast(const uint8_t* im, int w, int h, ptrdiff_t pitch, int threshold, int
 int so_get_sorted_keypoints(const uint8_t* im, int w, int h, ptrdiff_t pitch, size_t n_min_pts,
                             float* fast_threshold, so_keypoint* out, int cap);
 
+/* new_point.cpp:124 with the tie order fixed as in so_get_sorted_keypoints. */
+void so_sort_keypoints(so_keypoint* kps, int n);
+
+/* new_point.cpp:137-155: walks the sorted keypoints and keeps up to n whose distance to every
+ * occupied position (matches and lineMatches, xy pairs), to every point kept so far is >= min_dist
+ * and whose (2rx+1) x (2ry+1) neighbourhood lies inside the image.  sel receives indices into kps;
+ * returns how many were kept. */
+int so_select_new_points(const so_keypoint* kps, int nkps, const float* occ_xy, int nocc, int n,
+                         float min_dist, int rx, int ry, int w, int h, int* sel);
+
+/* feature.cpp:42-45 / lineFeature.cpp:7-10: the descriptor crop around pt2d; out (optional) receives
+ * the rows packed (pitch = *ow).  An empty crop reports 0 x 0. */
+int so_extract_descriptor(const uint8_t* im, int w, int h, ptrdiff_t pitch, float px, float py, int rx, int ry,
+                          uint8_t* out, int* ox, int* oy, int* ow, int* oh);
+
 /* ---- tests/test_matching.cpp:13-101 restated: generator + acceptance rule ------------------- */
 typedef struct so_proptest_case {
     int w, h, pw, ph;

@@ -256,6 +256,30 @@ def get_sorted_keypoints(ctx, im, n_min_pts, fast_threshold, cap=None):
     return out[:min(n.value, cap)].copy(), f.value
 
 
+def add_new_points(ctx, im, kps, occupied, n_new, min_dist, rx, ry, already_sorted=False, want_descriptors=True):
+    """SLAM::addNewLines' selection (new_point.cpp:137-155) for one frame: kps[n,3] in cv::FAST order
+    (or sorted), occupied[m,2].  Returns dict(sel, sorted, descriptors, rects)."""
+    im = _u8(im)
+    k = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 3)
+    occ = np.ascontiguousarray(occupied, dtype=np.float32).reshape(-1, 2)
+    sel = np.zeros(n_new, np.int32)
+    nsel = C.c_int32(0)
+    sorted_out = np.zeros_like(k)
+    one = (2 * rx + 1) * (2 * ry + 1)
+    desc = np.zeros(one * n_new, np.uint8)
+    res = (capi.DescResult * n_new)()
+    check(ctx.handle, lib().slam_hip_add_new_points(
+        ctx.handle, im.ctypes.data, im.shape[1], im.shape[0], im.strides[0], k.ctypes.data, len(k), int(already_sorted),
+        occ.ctypes.data if len(occ) else None, len(occ), n_new, min_dist, rx, ry, sel.ctypes.data, C.byref(nsel),
+        sorted_out.ctypes.data, desc.ctypes.data if want_descriptors else None, desc.size, res if want_descriptors else None))
+    n = nsel.value
+    out = dict(sel=sel[:n].copy(), sorted=sorted_out)
+    if want_descriptors:
+        out["rects"] = [(res[i].x0, res[i].y0, res[i].w, res[i].h) for i in range(n)]
+        out["descriptors"] = [desc[i * one:i * one + res[i].w * res[i].h].reshape(res[i].h, res[i].w).copy() for i in range(n)]
+    return out
+
+
 def debug_score_formulas(ctx, cc, si, sp):
     cc = np.ascontiguousarray(cc, np.uint64)
     si = np.ascontiguousarray(si, np.uint64)

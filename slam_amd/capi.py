@@ -53,6 +53,15 @@ class KeyPoint(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float), ("response", C.c_float)]
 
 
+class DescJob(C.Structure):
+    _fields_ = [("frame", C.c_int32), ("px", C.c_float), ("py", C.c_float), ("rx", C.c_int32), ("ry", C.c_int32),
+                ("reserved", C.c_int32), ("out_off", C.c_int64)]
+
+
+class DescResult(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("status", C.c_int32)]
+
+
 # every symbol include/slam_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -87,6 +96,13 @@ SIGNATURES = {
                                        C.c_int, _P, C.c_int, _P]),
     "slam_hip_get_sorted_keypoints": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                                 C.POINTER(C.c_float), _P, C.c_int, C.POINTER(C.c_int32)]),
+    "slam_hip_sort_keypoints_d": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "slam_hip_select_new_points_d": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, _P, _P]),
+    "slam_hip_extract_descriptors_d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, _P, C.c_int,
+                                                 _P, C.c_size_t, _P]),
+    "slam_hip_add_new_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                          C.c_float, C.c_int, C.c_int, _P, C.POINTER(C.c_int32), _P, _P, C.c_size_t, _P]),
     "slam_hip_debug_score_formulas": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "slam_hip_debug_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int, C.c_size_t]),
     "slam_hip_version": (C.c_char_p, []),

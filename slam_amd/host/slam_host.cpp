@@ -130,6 +130,37 @@ void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Proj
     }
 }
 
+std::vector<int> SLAM::selectNewPoints(const matb& im, const std::vector<cv::KeyPoint>& keypoints,
+                                       const std::vector<Match>& matches, const std::vector<Match>& lineMatches,
+                                       int n, float minDist, int rx, int ry, std::vector<matb>* descriptors) {
+    std::vector<int> out;
+    if (descriptors) descriptors->clear();
+    if (n <= 0 || keypoints.empty()) return out;
+    std::vector<slam_keypoint> kps(keypoints.size());
+    for (size_t i = 0; i < kps.size(); i++) { kps[i].x = keypoints[i].pt.x; kps[i].y = keypoints[i].pt.y; kps[i].response = keypoints[i].response; }
+    std::vector<float> occ;
+    for (const Match& m : matches) { occ.push_back(m.pos.x); occ.push_back(m.pos.y); }          // new_point.cpp:139-141
+    for (const Match& m : lineMatches) { occ.push_back(m.pos.x); occ.push_back(m.pos.y); }      // new_point.cpp:142-144
+    std::vector<int32_t> sel((size_t)n);
+    int32_t nsel = 0;
+    const size_t one = (size_t)(2 * rx + 1) * (2 * ry + 1);
+    std::vector<uint8_t> desc(descriptors ? one * (size_t)n : 0);
+    std::vector<slam_desc_result> res(descriptors ? (size_t)n : 0);
+    slamhip::check(slam_hip_add_new_points(slamhip::context(), im.data, im.cols, im.rows, im.step, kps.data(), (int)kps.size(), 1,
+                                           occ.empty() ? nullptr : occ.data(), (int)(occ.size() / 2), n, minDist, rx, ry,
+                                           sel.data(), &nsel, nullptr, descriptors ? desc.data() : nullptr, desc.size(),
+                                           descriptors ? res.data() : nullptr),
+                   "selectNewPoints");
+    out.assign(sel.begin(), sel.begin() + nsel);
+    if (descriptors)
+        for (int i = 0; i < nsel; i++) {
+            matb d(res[i].h, res[i].w);
+            for (int r = 0; r < res[i].h; r++) std::memcpy(d.ptr(r), &desc[one * (size_t)i + (size_t)r * res[i].w], (size_t)res[i].w);
+            descriptors->push_back(d);
+        }
+    return out;
+}
+
 void SLAM::getSortedKeyPoints(const matb& im, size_t nMinPts, std::vector<cv::KeyPoint>& out) const {
     slam_ctx* ctx = slamhip::context();
     int cap = 1 << 16;

@@ -82,6 +82,16 @@ public:
                             std::vector<Match>& matches, float threshold = .95f, int stride = 3,
                             std::vector<float>* responses = nullptr);
 
+    // The selection loop of SLAM::addNewLines (new_point.cpp:137-155) and the descriptor crop of the
+    // kept points (lineFeature.cpp:7-10): `keypoints` as returned by getSortedKeyPoints; a point is
+    // kept when it is at least minDist away from every match, line match and point kept before it and
+    // its (2rx+1) x (2ry+1) neighbourhood lies inside the image; at most n are kept.  Returns the
+    // indices into `keypoints`; descriptors (optional) receives one crop per kept point.
+    static std::vector<int> selectNewPoints(const matb& im, const std::vector<cv::KeyPoint>& keypoints,
+                                            const std::vector<Match>& matches, const std::vector<Match>& lineMatches,
+                                            int n, float minDist, int rx, int ry,
+                                            std::vector<matb>* descriptors = nullptr);
+
     // SLAM.hpp:118-119; fastThreshold is the mutable member of SLAM.hpp:22.
     void getSortedKeyPoints(const matb& im, size_t nMinPts, std::vector<cv::KeyPoint>& out) const;
     mutable float fastThreshold = 10.f;

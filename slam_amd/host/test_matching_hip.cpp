@@ -116,6 +116,23 @@ static bool test_pyramid_track_keypoints() {
     if ((int)kps.size() != n || slam.fastThreshold != thr) { printf("keypoints: %zu vs %d, thr %g vs %g\n", kps.size(), n, slam.fastThreshold, thr); return false; }
     for (int i = 0; i < n; i++)
         if (kps[i].pt.x != okp[i].x || kps[i].pt.y != okp[i].y || kps[i].response != okp[i].response || kps[i].size != 7.f) return false;
+
+    // new points: the selection of addNewLines against the oracle, with the matches above as occupied positions
+    std::vector<SLAM::Match> none;
+    std::vector<matb> descr;
+    const std::vector<int> picked = SLAM::selectNewPoints(im, kps, matches, none, 25, 14.f, 6, 6, &descr);
+    std::vector<float> occ;
+    for (size_t i = 0; i < matches.size(); i++) { occ.push_back(matches[i].pos.x); occ.push_back(matches[i].pos.y); }
+    std::vector<int> osel(25);
+    const int on = so_select_new_points(okp.data(), n, occ.data(), (int)matches.size(), 25, 14.f, 6, 6, w, h, osel.data());
+    if ((int)picked.size() != on || descr.size() != picked.size() || on == 0) { printf("selectNewPoints: %zu vs %d\n", picked.size(), on); return false; }
+    for (int i = 0; i < on; i++) {
+        if (picked[i] != osel[i]) return false;
+        uint8_t ref[13 * 13]; int ox, oy, ow, oh;
+        so_extract_descriptor(im.data, w, h, (ptrdiff_t)im.step, okp[osel[i]].x, okp[osel[i]].y, 6, 6, ref, &ox, &oy, &ow, &oh);
+        if (descr[i].cols != ow || descr[i].rows != oh) return false;
+        for (int r = 0; r < oh; r++) if (std::memcmp(descr[i].ptr(r), ref + (size_t)r * ow, ow) != 0) return false;
+    }
     return true;
 }
 

@@ -40,6 +40,8 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.TrackJob) == 48
     assert C.sizeof(capi.TrackResult) == 28
     assert C.sizeof(capi.KeyPoint) == 12
+    assert C.sizeof(capi.DescJob) == 32
+    assert C.sizeof(capi.DescResult) == 20
 
 
 def test_null_context_is_rejected_without_touching_a_gpu():

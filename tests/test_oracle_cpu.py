@@ -168,3 +168,33 @@ def test_golden_vectors_are_reproduced_by_the_oracle(oracle):
         for thr in (10, 40):
             assert np.array_equal(oracle.fast(f, thr, True), gold["fast/%d/t%d" % (i, thr)])
     assert np.array_equal(gold["kat/resize_6x6_by3"], (np.arange(36, dtype=np.uint8) * 5).reshape(6, 6)[1::3, 1::3])
+
+
+def test_new_point_selection_known_answers(oracle):
+    """new_point.cpp:137-155 by hand: sorted points on a line, minDist 10, one occupied position."""
+    kps = np.array([[50, 50, 90], [55, 50, 80], [61, 50, 70], [5, 50, 60], [80, 50, 50], [70.5, 50, 40]], np.float32)
+    occ = np.array([[82, 57]], np.float32)                   # 7.28 from (80,50): blocks it
+    sel = oracle.select_new_points(kps, occ, 10, 10.0, 8, 8, 100, 100)
+    # (55,50) is 5 from (50,50); (61,50) is 11 away -> kept; (5,50): 5-8 < 0 -> off the border; (80,50) blocked by the
+    # occupied position; (70.5,50) is 9.5 from (61,50) -> rejected
+    assert sel.tolist() == [0, 2]
+    assert oracle.select_new_points(kps, occ, 1, 10.0, 8, 8, 100, 100).tolist() == [0]        # n reached
+    assert oracle.select_new_points(kps, np.zeros((0, 2)), 10, 10.0, 8, 8, 100, 100).tolist() == [0, 2, 4]
+    # the distance test is strict: exactly minDist apart is accepted
+    two = np.array([[20, 20, 9], [30, 20, 8]], np.float32)
+    assert oracle.select_new_points(two, np.zeros((0, 2)), 5, 10.0, 1, 1, 100, 100).tolist() == [0, 1]
+    # border rule: y + ry >= h rejects, y + ry == h - 1 passes
+    edge = np.array([[50, 91, 9], [50, 92, 8]], np.float32)
+    assert oracle.select_new_points(edge, np.zeros((0, 2)), 5, 1.0, 8, 8, 100, 100).tolist() == [0]
+
+
+def test_descriptor_crop_known_answers(oracle):
+    im = np.arange(40 * 30, dtype=np.uint32).reshape(30, 40).astype(np.uint8)
+    d, rect = oracle.extract_descriptor(im, 10.0, 12.0, 3, 2)
+    assert rect == (7, 10, 7, 5) and np.array_equal(d, im[10:15, 7:14])
+    d, rect = oracle.extract_descriptor(im, 1.5, 0.4, 3, 2)     # iround(-1.5) = -2 -> 0; iround(5.5) = 6
+    assert rect == (0, 0, 6, 3) and np.array_equal(d, im[0:3, 0:6])
+    d, rect = oracle.extract_descriptor(im, 100.0, 5.0, 3, 2)
+    assert rect == (0, 0, 0, 0) and d.size == 0
+    srt = oracle.sort_keypoints(np.array([[5, 1, 3], [2, 1, 7], [9, 0, 3], [1, 1, 3]], np.float32))
+    assert srt.tolist() == [[2, 1, 7], [9, 0, 3], [1, 1, 3], [5, 1, 3]]
