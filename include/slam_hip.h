@@ -244,6 +244,51 @@ int slam_hip_add_new_points(slam_ctx* ctx, const uint8_t* im, int w, int h, size
                             uint8_t* descr_out, size_t descr_bytes, slam_desc_result* descr_res);
 
 /* ---------------------------------------------------------------------------------------------
+ * Template projection — replaces SLAM::Feature::project (SLAM.hpp:58-60, feature.cpp:53-100): the
+ * descriptor is warped by the predicted homography into `proj`, and an all-ones image of the same
+ * size into its {0,1} `mask` (cv::warpPerspective with WARP_INVERSE_MAP, INTER_LINEAR and
+ * INTER_NEAREST, constant border 0; feature.cpp:96-98).  Outputs are written as packed rows into a
+ * byte blob — the same blob slam_hip_track_batch_d reads its templates from, so projected
+ * templates never leave the device.
+ * ------------------------------------------------------------------------------------------- */
+/* The matrix steps of feature.cpp:61-94 (pure host arithmetic, no device work).  P = state.P (3x4),
+ * B = Feature::B (4x3; rows 0-2 of column 2 are replaced by p3d as feature.cpp:61 does), row-major.
+ * loc = `location` (x, y, width, height), m = Am as handed to warpPerspective (3x3 row-major),
+ * *valid = 0 when project returns an empty Mat (feature.cpp:56-59, 84-86). */
+int slam_hip_project_setup(const float* P, const float* B, const float* p3d, int dw, int dh,
+                           int32_t* loc, float* m, int32_t* valid);
+
+typedef struct slam_warp_job {
+    int64_t desc_off;       /* descriptor in the source blob, pitch dw */
+    int64_t proj_off;       /* proj in the output blob, pitch ow */
+    int64_t mask_off;       /* mask in the output blob, pitch ow; -1: no mask wanted */
+    int32_t dw, dh;         /* descriptor size */
+    int32_t ow, oh;         /* location.width, location.height; 0 = empty projection, nothing is written */
+    float   m[9];           /* Am: maps the homogeneous proj pixel (x, y, 1) into descriptor coordinates */
+    int32_t reserved;
+} slam_warp_job;
+
+/* Device tables, asynchronous, allocates nothing.  d_status (optional, njobs ints) receives 0 or
+ * SLAM_HIP_EINVAL per job (offsets outside the blobs, sizes out of range, non-finite matrix).
+ * max_out_pixels: the largest ow*oh of the batch if the caller knows it (spreads large outputs over
+ * more workgroups), else 0. */
+int slam_hip_warp_batch_d(slam_ctx* ctx, const uint8_t* d_desc, size_t desc_bytes,
+                          const slam_warp_job* d_jobs, int njobs, uint8_t* d_out, size_t out_bytes,
+                          int32_t* d_status, int max_out_pixels);
+/* Feature::project for one feature, host pointers: proj and mask (pitch loc[2]) must hold cap bytes
+ * each; SLAM_HIP_ECAP when they are too small. */
+int slam_hip_project(slam_ctx* ctx, const uint8_t* descr, int dw, int dh, size_t pitch,
+                     const float* P, const float* B, const float* p3d,
+                     uint8_t* proj, uint8_t* mask, size_t cap, int32_t* loc, int32_t* valid);
+/* Feature::track as the reference runs it (feature.cpp:109-172) for a batch of features, host tables:
+ * wjobs[i] (desc_off, dw, dh, ow, oh, m from slam_hip_project_setup; the output offsets are assigned
+ * here) is projected on the device and searched with tjobs[i] (frame, px, py, threshold, stride; its
+ * template fields are filled in here) without the templates visiting the host. */
+int slam_hip_project_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_warp_job* wjobs,
+                                 const slam_track_job* tjobs, int njobs, const uint8_t* desc_blob,
+                                 size_t desc_bytes, slam_track_result* out);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (used by the parity tests; no reference counterpart).
  * ------------------------------------------------------------------------------------------- */
 /* Evaluates the two score formulas of matching.cpp on the device for n triples of exact integer

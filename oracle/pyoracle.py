@@ -38,6 +38,10 @@ class KeyPoint(C.Structure):
     _fields_ = [("x", C.c_float), ("y", C.c_float), ("response", C.c_float)]
 
 
+class Projection(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int), ("m", C.c_float * 9), ("valid", C.c_int)]
+
+
 class PropCase(C.Structure):
     _fields_ = [("w", C.c_int), ("h", C.c_int), ("pw", C.c_int), ("ph", C.c_int),
                 ("xpatch", C.c_int), ("ypatch", C.c_int),
@@ -89,6 +93,11 @@ def lib():
         L.so_extract_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_float, C.c_float, C.c_int, C.c_int,
                                             C.c_void_p] + [C.POINTER(C.c_int)] * 4
         L.so_extract_descriptor.restype = C.c_int
+        L.so_project_setup.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Projection)]
+        L.so_project_setup.restype = C.c_int
+        L.so_warp_perspective_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_ssize_t]
+        L.so_warp_perspective_u8.restype = C.c_int
         L.so_proptest_srand.argtypes = [C.c_uint]
         L.so_proptest_srand.restype = None
         L.so_proptest_next.argtypes = [C.c_int, C.c_int, C.POINTER(PropCase)]
@@ -250,6 +259,38 @@ def extract_descriptor(im, px, py, rx, ry):
                                 *[C.byref(v) for v in r])
     x0, y0, w, h = [v.value for v in r]
     return out[:w * h].reshape(h, w).copy(), (x0, y0, w, h)
+
+
+def project_setup(P, B, p3d, dw, dh):
+    """feature.cpp:61-94.  P 3x4, B 4x3, p3d 3 (float32).  Returns dict(loc=(x, y, w, h), m=3x3 float32, valid)."""
+    P = np.ascontiguousarray(P, np.float32).reshape(3, 4)
+    B = np.ascontiguousarray(B, np.float32).reshape(4, 3)
+    p = np.ascontiguousarray(p3d, np.float32).reshape(3)
+    out = Projection()
+    lib().so_project_setup(P.ctypes.data, B.ctypes.data, p.ctypes.data, dw, dh, C.byref(out))
+    return dict(loc=(out.x, out.y, out.w, out.h), m=np.array(out.m, np.float32).reshape(3, 3), valid=bool(out.valid))
+
+
+def warp_perspective(src, M, dw, dh, nearest=False):
+    """cv::warpPerspective(src, dst, M, Size(dw, dh), WARP_INVERSE_MAP | INTER_LINEAR or INTER_NEAREST)."""
+    src = _u8(src)
+    M = np.ascontiguousarray(M, np.float32).reshape(9)
+    dst = np.empty((dh, dw), np.uint8)
+    rc = lib().so_warp_perspective_u8(src.ctypes.data, src.shape[1], src.shape[0], src.strides[0], M.ctypes.data,
+                                      int(bool(nearest)), dst.ctypes.data, dw, dh, dw)
+    if rc != 0:
+        raise ValueError("so_warp_perspective_u8: bad arguments")
+    return dst
+
+
+def project(descriptor, P, B, p3d):
+    """Feature::project (feature.cpp:53-100): returns (proj, mask, location) - empty arrays when the projection is empty."""
+    d = _u8(descriptor)
+    s = project_setup(P, B, p3d, d.shape[1], d.shape[0])
+    if not s["valid"]:
+        return np.zeros((0, 0), np.uint8), np.zeros((0, 0), np.uint8), s["loc"]
+    _, _, w, h = s["loc"]
+    return warp_perspective(d, s["m"], w, h, False), warp_perspective(np.ones_like(d), s["m"], w, h, True), s["loc"]
 
 
 class PropTest:

@@ -534,6 +534,136 @@ int so_extract_descriptor(const uint8_t* im, int w, int h, ptrdiff_t pitch, floa
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* feature.cpp:53-100  SLAM::Feature::project                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The float matrix steps of feature.cpp:61-94 with OpenCV 2.4's arithmetic:
+ *   P*B (3x4 by 4x3)        generic cv::gemm for CV_32F: products accumulated in double over k = 0..3,
+ *                           the sum rounded to float;
+ *   A*p, Am*p (3x3 by 3x1)  gemm's small-matrix case: a0*b0 + a1*b1 + a2*b2 evaluated in float;
+ *   row /= s                convertTo(row, -1, 1./s): each element times (float)(1./(double)s), in float;
+ *   A.inv()                 cv::invert's closed form for 3x3 CV_32F: cofactors and determinant in
+ *                           double, each entry rounded to float; a zero determinant gives the zero matrix. */
+int so_project_setup(const float* P, const float* B, const float* p3d, int dw, int dh, so_projection* out) {
+    memset(out, 0, sizeof(*out));
+    if (dw <= 0 || dh <= 0) return 0;                                 /* feature.cpp:56-59 */
+    float Bm[12];
+    memcpy(Bm, B, sizeof(Bm));
+    Bm[0 * 3 + 2] = p3d[0]; Bm[1 * 3 + 2] = p3d[1]; Bm[2 * 3 + 2] = p3d[2];   /* feature.cpp:61 */
+    float A[9];
+    for (int i = 0; i < 3; i++)                                       /* feature.cpp:62 */
+        for (int j = 0; j < 3; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += (double)P[i * 4 + k] * (double)Bm[k * 3 + j];
+            A[i * 3 + j] = (float)s;
+        }
+    const int dx = dw / 2, dy = dh / 2;                               /* feature.cpp:63 */
+    const float gc[4][2] = {{(float)-dx, (float)-dy}, {(float)-dx, (float)dy}, {(float)dx, (float)dy}, {(float)dx, (float)-dy}};
+    int xmin = 1000000, xmax = -1000000, ymin = 1000000, ymax = -1000000;
+    for (int i = 0; i < 4; i++) {                                     /* feature.cpp:67-79 */
+        float c[3];
+        for (int r = 0; r < 3; r++) c[r] = A[r * 3 + 0] * gc[i][0] + A[r * 3 + 1] * gc[i][1] + A[r * 3 + 2] * 1.0f;
+        const float inv = (float)(1.0 / (double)c[2]);
+        const float cx = c[0] * inv, cy = c[1] * inv;
+        if (!(fabsf(cx) < 1e9f) || !(fabsf(cy) < 1e9f)) return 0;     /* not representable as int: treated as empty */
+        xmin = imin(xmin, (int)ceil((double)cx)); xmax = imax(xmax, (int)floor((double)cx));
+        ymin = imin(ymin, (int)ceil((double)cy)); ymax = imax(ymax, (int)floor((double)cy));
+    }
+    out->x = xmin; out->y = ymin;                                     /* feature.cpp:80-83 */
+    out->w = imax(0, xmax - xmin); out->h = imax(0, ymax - ymin);
+    if (out->w == 0 || out->h == 0 || out->w > 500 || out->h > 500) return 0;   /* feature.cpp:84-86 */
+    /* feature.cpp:90  Am = A.inv() */
+    const double a00 = A[0], a01 = A[1], a02 = A[2], a10 = A[3], a11 = A[4], a12 = A[5], a20 = A[6], a21 = A[7], a22 = A[8];
+    double d = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+    float Am[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (d != 0.0) {
+        d = 1.0 / d;
+        Am[0] = (float)((a11 * a22 - a12 * a21) * d); Am[1] = (float)((a02 * a21 - a01 * a22) * d); Am[2] = (float)((a01 * a12 - a02 * a11) * d);
+        Am[3] = (float)((a12 * a20 - a10 * a22) * d); Am[4] = (float)((a00 * a22 - a02 * a20) * d); Am[5] = (float)((a02 * a10 - a00 * a12) * d);
+        Am[6] = (float)((a10 * a21 - a11 * a20) * d); Am[7] = (float)((a01 * a20 - a00 * a21) * d); Am[8] = (float)((a00 * a11 - a01 * a10) * d);
+    }
+    /* feature.cpp:91-92  Am.col(2) = Am * (xmin, ymin, 1) */
+    const float fx = (float)xmin, fy = (float)ymin;
+    float c2[3];
+    for (int r = 0; r < 3; r++) c2[r] = Am[r * 3 + 0] * fx + Am[r * 3 + 1] * fy + Am[r * 3 + 2] * 1.0f;
+    for (int r = 0; r < 3; r++) Am[r * 3 + 2] = c2[r];
+    /* feature.cpp:93-94  Am.row(0) += dx * Am.row(2); Am.row(1) += dy * Am.row(2) */
+    for (int j = 0; j < 3; j++) Am[0 * 3 + j] = Am[0 * 3 + j] + Am[2 * 3 + j] * (float)dx;
+    for (int j = 0; j < 3; j++) Am[1 * 3 + j] = Am[1 * 3 + j] + Am[2 * 3 + j] * (float)dy;
+    for (int j = 0; j < 9; j++) if (!(fabsf(Am[j]) < 1e30f)) { out->w = 0; out->h = 0; return 0; }   /* non-finite map: empty */
+    memcpy(out->m, Am, sizeof(Am));
+    out->valid = 1;
+    return 0;
+}
+
+/* cv::warpPerspective(src, dst, M, Size(dw, dh), WARP_INVERSE_MAP | interpolation) for CV_8UC1 with
+ * the default BORDER_CONSTANT, value 0 (feature.cpp:96-98), OpenCV 2.4 imgwarp.cpp:
+ *   - M is converted to double; the destination is walked in blocks of bw0 columns
+ *     (bh0 = min(16, h); bw0 = min(1024/bh0, w)); per row of a block X0 = M0*x + M1*y + M2 (x = block
+ *     start) and per pixel (X0 + M0*x1) * W with W = 1/(W0 + M6*x1) (nearest) or 32/(...) (linear);
+ *     a zero denominator gives W = 0; the products are clamped to the int range and rounded
+ *     half-to-even (cvRound);
+ *   - nearest: remap takes src(sat_s16(Y), sat_s16(X)) or 0 outside;
+ *   - linear: integer part sat_s16(X >> 5), 5 fractional bits per axis, the four taps weighted by
+ *     (32-fx)(32-fy)*32 etc. (the 15-bit table; its (0,0) entry is stored as 32767,0,0,1, which yields
+ *     the same byte as 32768,0,0,0 for every tap combination), taps outside the image read 0,
+ *     result (sum + 16384) >> 15. */
+int so_warp_perspective_u8(const uint8_t* src, int sw, int sh, ptrdiff_t spitch, const float* Mf, int nearest,
+                           uint8_t* dst, int dw, int dh, ptrdiff_t dpitch) {
+    if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return -1;
+    double M[9];
+    for (int i = 0; i < 9; i++) M[i] = (double)Mf[i];
+    int bh0 = imin(16, dh);
+    const int bw0 = imin(1024 / bh0, dw);
+    for (int y = 0; y < dh; y++) {
+        for (int x = 0; x < dw; x += bw0) {
+            const int bw = imin(bw0, dw - x);
+            const double X0 = M[0] * x + M[1] * y + M[2];
+            const double Y0 = M[3] * x + M[4] * y + M[5];
+            const double W0 = M[6] * x + M[7] * y + M[8];
+            for (int x1 = 0; x1 < bw; x1++) {
+                double W = W0 + M[6] * x1;
+                if (nearest) W = W != 0.0 ? 1. / W : 0.0; else W = W != 0.0 ? 32. / W : 0.0;
+                const double fX = fmax((double)INT32_MIN, fmin((double)INT32_MAX, (X0 + M[0] * x1) * W));
+                const double fY = fmax((double)INT32_MIN, fmin((double)INT32_MAX, (Y0 + M[3] * x1) * W));
+                const int X = cv_round(fX), Y = cv_round(fY);
+                uint8_t* D = dst + (ptrdiff_t)y * dpitch + x + x1;
+                if (nearest) {
+                    const int sx = sat_s16(X), sy = sat_s16(Y);
+                    *D = ((unsigned)sx < (unsigned)sw && (unsigned)sy < (unsigned)sh) ? src[(ptrdiff_t)sy * spitch + sx] : 0;
+                } else {
+                    const int sx = sat_s16(X >> 5), sy = sat_s16(Y >> 5);
+                    const int ax = X & 31, ay = Y & 31;
+                    const int w0 = (32 - ax) * (32 - ay) * 32, w1 = ax * (32 - ay) * 32, w2 = (32 - ax) * ay * 32, w3 = ax * ay * 32;
+                    const int in_x0 = (unsigned)sx < (unsigned)sw, in_x1 = (unsigned)(sx + 1) < (unsigned)sw;
+                    const int in_y0 = (unsigned)sy < (unsigned)sh, in_y1 = (unsigned)(sy + 1) < (unsigned)sh;
+                    const int v0 = (in_x0 && in_y0) ? src[(ptrdiff_t)sy * spitch + sx] : 0;
+                    const int v1 = (in_x1 && in_y0) ? src[(ptrdiff_t)sy * spitch + sx + 1] : 0;
+                    const int v2 = (in_x0 && in_y1) ? src[(ptrdiff_t)(sy + 1) * spitch + sx] : 0;
+                    const int v3 = (in_x1 && in_y1) ? src[(ptrdiff_t)(sy + 1) * spitch + sx + 1] : 0;
+                    *D = (uint8_t)((v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3 + (1 << 14)) >> 15);
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+int so_project(const uint8_t* descr, int dw, int dh, ptrdiff_t dpitch, const float* P, const float* B, const float* p3d,
+               uint8_t* proj, uint8_t* mask, size_t cap, so_projection* out) {
+    so_project_setup(P, B, p3d, dw, dh, out);
+    if (!out->valid) return 0;
+    if ((size_t)out->w * (size_t)out->h > cap) return -1;
+    so_warp_perspective_u8(descr, dw, dh, dpitch, out->m, 0, proj, out->w, out->h, out->w);     /* feature.cpp:96 */
+    uint8_t* ones = (uint8_t*)malloc((size_t)dw * dh);
+    if (!ones) return -1;
+    memset(ones, 1, (size_t)dw * dh);
+    so_warp_perspective_u8(ones, dw, dh, dw, out->m, 1, mask, out->w, out->h, out->w);            /* feature.cpp:97-98 */
+    free(ones);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* tests/test_matching.cpp:13-101 restated                                                    */
 /* ------------------------------------------------------------------------------------------ */
 

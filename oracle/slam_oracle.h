@@ -11,6 +11,9 @@
  *   imagePyramid.hpp:15-30    ImagePyramid<T> constructor  -> so_pyramid_level_size, so_resize_u8_linear
  *   feature.cpp:117-172       SLAM::Feature::track         -> so_track
  *   new_point.cpp:109-127     SLAM::getSortedKeyPoints     -> so_get_sorted_keypoints
+ *   new_point.cpp:137-155     SLAM::addNewLines selection  -> so_select_new_points
+ *   feature.cpp:36-51         Feature::newDescriptor crop  -> so_extract_descriptor
+ *   feature.cpp:53-100        SLAM::Feature::project       -> so_project_setup, so_warp_perspective_u8
  *   tests/test_matching.cpp   property test generator      -> so_proptest_*
  *
  * The arithmetic of cv::resize, cv::matchTemplate, cv::norm / Mat::dot / Mat::mul,
@@ -113,6 +116,27 @@ int so_select_new_points(const so_keypoint* kps, int nkps, const float* occ_xy, 
  * the rows packed (pitch = *ow).  An empty crop reports 0 x 0. */
 int so_extract_descriptor(const uint8_t* im, int w, int h, ptrdiff_t pitch, float px, float py, int rx, int ry,
                           uint8_t* out, int* ox, int* oy, int* ow, int* oh);
+
+/* feature.cpp:53-100 (SLAM::Feature::project).  PARITY UNPINNED: no test of the reference pins it
+ * (tests/test_project.cpp is disabled and asserts nothing); cv::warpPerspective / cv::remap,
+ * cv::gemm and cv::invert are restated from OpenCV 2.4's published algorithms. */
+typedef struct so_projection {
+    int x, y, w, h;    /* `location` (feature.cpp:80-83); w x h is the size of proj and mask */
+    float m[9];        /* Am as passed to warpPerspective (feature.cpp:90-94), row-major */
+    int valid;         /* 0: project returns an empty Mat (feature.cpp:56-59, 84-86) */
+} so_projection;
+
+/* feature.cpp:61-94: P = state.P (3x4), B (4x3, column 2 rows 0-2 are replaced by p3d), row-major. */
+int so_project_setup(const float* P, const float* B, const float* p3d, int dw, int dh, so_projection* out);
+
+/* cv::warpPerspective(src, dst, M, Size(dw,dh), WARP_INVERSE_MAP | (nearest ? INTER_NEAREST :
+ * INTER_LINEAR)) on 8-bit single channel, constant border 0.  Returns 0 / -1. */
+int so_warp_perspective_u8(const uint8_t* src, int sw, int sh, ptrdiff_t spitch, const float* M, int nearest,
+                           uint8_t* dst, int dw, int dh, ptrdiff_t dpitch);
+
+/* The whole of feature.cpp:53-100: proj and mask (pitch out->w) must hold cap bytes each. */
+int so_project(const uint8_t* descr, int dw, int dh, ptrdiff_t dpitch, const float* P, const float* B, const float* p3d,
+               uint8_t* proj, uint8_t* mask, size_t cap, so_projection* out);
 
 /* ---- tests/test_matching.cpp:13-101 restated: generator + acceptance rule ------------------- */
 typedef struct so_proptest_case {

@@ -280,6 +280,70 @@ def add_new_points(ctx, im, kps, occupied, n_new, min_dist, rx, ry, already_sort
     return out
 
 
+def project_setup(P, B, p3d, dw, dh):
+    """feature.cpp:61-94 (host arithmetic of the library): returns dict(loc=(x, y, w, h), m=3x3 float32, valid)."""
+    P = np.ascontiguousarray(P, np.float32).reshape(3, 4)
+    B = np.ascontiguousarray(B, np.float32).reshape(4, 3)
+    p = np.ascontiguousarray(p3d, np.float32).reshape(3)
+    loc = np.zeros(4, np.int32)
+    m = np.zeros(9, np.float32)
+    valid = C.c_int32(0)
+    rc = lib().slam_hip_project_setup(P.ctypes.data, B.ctypes.data, p.ctypes.data, dw, dh, loc.ctypes.data, m.ctypes.data,
+                                      C.byref(valid))
+    if rc != capi.OK:
+        raise SlamHipError(rc, "project_setup")
+    return dict(loc=tuple(int(v) for v in loc), m=m.reshape(3, 3), valid=bool(valid.value))
+
+
+def project(ctx, descriptor, P, B, p3d):
+    """SLAM::Feature::project (feature.cpp:53-100): returns (proj, mask, location); empty arrays for an empty projection."""
+    d = _u8(descriptor)
+    P = np.ascontiguousarray(P, np.float32).reshape(3, 4)
+    B = np.ascontiguousarray(B, np.float32).reshape(4, 3)
+    p = np.ascontiguousarray(p3d, np.float32).reshape(3)
+    cap = 500 * 500
+    proj = np.zeros(cap, np.uint8)
+    mask = np.zeros(cap, np.uint8)
+    loc = np.zeros(4, np.int32)
+    valid = C.c_int32(0)
+    check(ctx.handle, lib().slam_hip_project(ctx.handle, d.ctypes.data, d.shape[1], d.shape[0], d.strides[0], P.ctypes.data,
+                                             B.ctypes.data, p.ctypes.data, proj.ctypes.data, mask.ctypes.data, cap,
+                                             loc.ctypes.data, C.byref(valid)))
+    loc = tuple(int(v) for v in loc)
+    if not valid.value:
+        return np.zeros((0, 0), np.uint8), np.zeros((0, 0), np.uint8), loc
+    n = loc[2] * loc[3]
+    return proj[:n].reshape(loc[3], loc[2]).copy(), mask[:n].reshape(loc[3], loc[2]).copy(), loc
+
+
+def project_track_batch(ctx, pyr, jobs):
+    """SLAM::Feature::track as the reference runs it (project, then the level walk; feature.cpp:102-173).
+    jobs: list of dicts(frame, descriptor, P, B, p3d, px, py, threshold, stride); the projected templates stay on
+    the device."""
+    n = len(jobs)
+    blob = Blob()
+    wj = (capi.WarpJob * max(n, 1))()
+    tj = (TrackJob * max(n, 1))()
+    for i, j in enumerate(jobs):
+        d = _u8(j["descriptor"])
+        s = project_setup(j["P"], j["B"], j["p3d"], d.shape[1], d.shape[0])
+        w, t = wj[i], tj[i]
+        w.desc_off = blob.add(d)
+        w.dh, w.dw = d.shape
+        w.ow, w.oh = (s["loc"][2], s["loc"][3]) if s["valid"] else (0, 0)
+        for k in range(9):
+            w.m[k] = float(s["m"].reshape(9)[k])
+        t.frame = j.get("frame", 0)
+        t.px, t.py = float(j["px"]), float(j["py"])
+        t.threshold = float(j["threshold"])
+        t.stride = int(j["stride"])
+    b = blob.bytes()
+    res = (TrackResult * max(n, 1))()
+    check(ctx.handle, lib().slam_hip_project_track_batch(ctx.handle, pyr.handle, wj, tj, n, b.ctypes.data, b.size, res))
+    return [dict(x=r.x, y=r.y, response=r.response, dx=r.dx, dy=r.dy, levels_run=r.levels_run, status=r.status)
+            for r in res[:n]]
+
+
 def debug_score_formulas(ctx, cc, si, sp):
     cc = np.ascontiguousarray(cc, np.uint64)
     si = np.ascontiguousarray(si, np.uint64)

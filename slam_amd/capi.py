@@ -62,6 +62,11 @@ class DescResult(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("status", C.c_int32)]
 
 
+class WarpJob(C.Structure):
+    _fields_ = [("desc_off", C.c_int64), ("proj_off", C.c_int64), ("mask_off", C.c_int64), ("dw", C.c_int32), ("dh", C.c_int32),
+                ("ow", C.c_int32), ("oh", C.c_int32), ("m", C.c_float * 9), ("reserved", C.c_int32)]
+
+
 # every symbol include/slam_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -103,6 +108,10 @@ SIGNATURES = {
                                                  _P, C.c_size_t, _P]),
     "slam_hip_add_new_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int,
                                           C.c_float, C.c_int, C.c_int, _P, C.POINTER(C.c_int32), _P, _P, C.c_size_t, _P]),
+    "slam_hip_project_setup": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, C.POINTER(C.c_int32)]),
+    "slam_hip_warp_batch_d": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, _P, C.c_size_t, _P, C.c_int]),
+    "slam_hip_project": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, _P, _P, _P, _P, C.c_size_t, _P, C.POINTER(C.c_int32)]),
+    "slam_hip_project_track_batch": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "slam_hip_debug_score_formulas": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "slam_hip_debug_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int, C.c_size_t]),
     "slam_hip_version": (C.c_char_p, []),

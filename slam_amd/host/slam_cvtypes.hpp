@@ -76,6 +76,8 @@ private:
     std::shared_ptr<std::vector<T>> buf_;
 };
 
+struct Mat;   // only ever passed as a (NULL) pointer: Feature::track's debug display argument
+
 struct KeyPoint {
     Point2f pt;
     float size, angle, response;

@@ -110,6 +110,127 @@ cv::Point2i SLAM::Feature::track(const ImagePyramid<byte>& pyramid, const Projec
     return cv::Point2i(r.x, r.y);
 }
 
+SLAM::CameraState::CameraState(const matf& P_, const matf& t_) : P(P_), KR(3, 3), t(t_) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KR(r, c) = P(r, c);      // SLAM.hpp:136
+}
+
+// SLAM.hpp:150-158 with OpenCV 2.4's arithmetic: KR*(p - t) is cv::gemm's 3x3 small-matrix case (float),
+// P*p its generic case (products summed in double), a /= a(2) multiplies by (float)(1./a(2)).
+matf SLAM::CameraState::project(const matf& p) const {
+    float a[3];
+    if (p.rows == 3) {
+        const float d0 = p(0, 0) - t(0, 0), d1 = p(1, 0) - t(1, 0), d2 = p(2, 0) - t(2, 0);
+        for (int r = 0; r < 3; r++) a[r] = KR(r, 0) * d0 + KR(r, 1) * d1 + KR(r, 2) * d2;
+    } else {
+        for (int r = 0; r < 3; r++) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; k++) acc += (double)P(r, k) * (double)p(k, 0);
+            a[r] = (float)acc;
+        }
+    }
+    const float s = (float)(1.0 / (double)a[2]);
+    matf out(2, 1);
+    out(0, 0) = a[0] * s;
+    out(1, 0) = a[1] * s;
+    return out;
+}
+
+namespace {
+
+// feature.cpp:61-94 through the library's host arithmetic; fills the warp job's matrix and output size.
+bool setup_projection(const SLAM::Feature& f, const SLAM::CameraState& state, const matf& p3d, slam_warp_job& job,
+                      cv::Rect& location) {
+    std::memset(&job, 0, sizeof(job));
+    location = cv::Rect(0, 0, 0, 0);
+    if (f.descriptor.cols <= 0 || f.descriptor.rows <= 0) return false;              // feature.cpp:56-59
+    if (f.B.rows != 4 || f.B.cols != 3 || state.P.rows != 3 || state.P.cols != 4 || p3d.rows != 3)
+        throw std::invalid_argument("Feature::project: B must be 4x3, state.P 3x4, p3d 3x1");
+    for (int r = 0; r < 3; r++) f.B(r, 2) = p3d(r, 0);                                // feature.cpp:61
+    float P[12], B[12], p[3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) P[r * 4 + c] = state.P(r, c);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 3; c++) B[r * 3 + c] = f.B(r, c);
+    for (int r = 0; r < 3; r++) p[r] = p3d(r, 0);
+    int32_t loc[4], valid = 0;
+    if (slam_hip_project_setup(P, B, p, f.descriptor.cols, f.descriptor.rows, loc, job.m, &valid) != SLAM_HIP_OK)
+        throw std::invalid_argument("Feature::project: bad arguments");
+    location = cv::Rect(loc[0], loc[1], loc[2], loc[3]);
+    if (!valid) return false;
+    job.dw = f.descriptor.cols; job.dh = f.descriptor.rows; job.ow = loc[2]; job.oh = loc[3];
+    return true;
+}
+
+void track_features(const ImagePyramid<byte>& pyramid, const SLAM::CameraState& state,
+                    const SLAM::Feature* const* feats, const matf* const* p3ds, size_t n, float threshold, int stride,
+                    std::vector<slam_track_result>& res) {
+    std::vector<slam_warp_job> wj(n);
+    std::vector<slam_track_job> tj(n);
+    std::vector<uint8_t> blob;
+    for (size_t i = 0; i < n; i++) {
+        cv::Rect loc;
+        const SLAM::Feature& f = *feats[i];
+        setup_projection(f, state, *p3ds[i], wj[i], loc);       // an empty projection leaves ow = oh = 0
+        wj[i].desc_off = (int64_t)blob.size();
+        for (int r = 0; r < f.descriptor.rows; r++) blob.insert(blob.end(), f.descriptor.ptr(r), f.descriptor.ptr(r) + f.descriptor.cols);
+        const matf p2d = state.project(*p3ds[i]);                // feature.cpp:117
+        std::memset(&tj[i], 0, sizeof(tj[i]));
+        tj[i].frame = 0; tj[i].px = p2d(0, 0); tj[i].py = p2d(1, 0); tj[i].threshold = threshold; tj[i].stride = stride;
+    }
+    if (blob.empty()) blob.push_back(0);
+    res.resize(n);
+    slamhip::check(slam_hip_project_track_batch(slamhip::context(), pyramid.device(), wj.data(), tj.data(), (int)n, blob.data(),
+                                                blob.size(), res.data()),
+                   "Feature::track");
+    for (size_t i = 0; i < n; i++)
+        if (res[i].status != SLAM_HIP_OK) throw std::invalid_argument("Feature::track: job rejected by the device");
+}
+
+}  // namespace
+
+matb SLAM::Feature::project(const CameraState& state, const matf& p3d, matb& mask, cv::Rect& location) const {
+    slam_warp_job job;
+    if (!setup_projection(*this, state, p3d, job, location)) return matb();
+    float P[12], Bm[12], p[3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) P[r * 4 + c] = state.P(r, c);
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 3; c++) Bm[r * 3 + c] = B(r, c);
+    for (int r = 0; r < 3; r++) p[r] = p3d(r, 0);
+    matb proj(location.height, location.width);
+    mask = matb(location.height, location.width);
+    int32_t loc[4], valid = 0;
+    slamhip::check(slam_hip_project(slamhip::context(), descriptor.data, descriptor.cols, descriptor.rows, descriptor.step, P, Bm, p,
+                                    proj.data, mask.data, (size_t)location.width * location.height, loc, &valid),
+                   "Feature::project");
+    return proj;
+}
+
+cv::Point2i SLAM::Feature::track(const ImagePyramid<byte>& pyramid, const CameraState& state, const matf& p3d,
+                                 float threshold, int stride, float& response, cv::Mat*) const {
+    const Feature* f = this;
+    const matf* p = &p3d;
+    std::vector<slam_track_result> res;
+    track_features(pyramid, state, &f, &p, 1, threshold, stride, res);
+    response = res[0].response;
+    return cv::Point2i(res[0].x, res[0].y);
+}
+
+void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const CameraState& state, const std::vector<Feature>& features,
+                       const std::vector<matf>& p3ds, std::vector<Match>& matches, float threshold, int stride,
+                       std::vector<float>* responses) {
+    matches.clear();
+    if (features.size() != p3ds.size()) throw std::invalid_argument("matchPoints: one p3d per feature");
+    if (responses) responses->assign(features.size(), -1.f);
+    if (features.empty()) return;
+    std::vector<const Feature*> fp(features.size());
+    std::vector<const matf*> pp(features.size());
+    for (size_t i = 0; i < features.size(); i++) { fp[i] = &features[i]; pp[i] = &p3ds[i]; }
+    std::vector<slam_track_result> res;
+    track_features(pyramid, state, fp.data(), pp.data(), features.size(), threshold, stride, res);
+    for (size_t i = 0; i < res.size(); i++) {
+        if (responses) (*responses)[i] = res[i].response;
+        if (res[i].response > threshold)      // matching.cpp:262
+            matches.push_back(Match(cv::Point2f((float)res[i].x, (float)res[i].y), (int)i));
+    }
+}
+
 void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Projection>& features,
                        std::vector<Match>& matches, float threshold, int stride, std::vector<float>* responses) {
     matches.clear();

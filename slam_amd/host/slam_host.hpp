@@ -3,7 +3,8 @@
 // the reference so that its call sites compile against this header unchanged:
 //   SLAM::matchFeatureInArea       SLAM.hpp:92-98, matching.cpp:9-228
 //   ImagePyramid<byte>             imagePyramid.hpp:9-34
-//   SLAM::Feature::track           SLAM.hpp:62-65, feature.cpp:102-173   (the level walk; see below)
+//   SLAM::Feature::project         SLAM.hpp:57-58, feature.cpp:53-100
+//   SLAM::Feature::track           SLAM.hpp:62-65, feature.cpp:102-173
 //   SLAM::getSortedKeyPoints       SLAM.hpp:118-119, new_point.cpp:113-127
 //   SLAM::matchPoints              SLAM.hpp:106-107, matching.cpp:230-269 (batched over features)
 // Device errors (no GPU, failed allocation) are reported by std::runtime_error; the reference's own
@@ -19,6 +20,7 @@
 
 typedef unsigned char byte;
 typedef cv::Mat_<byte> matb;
+typedef cv::Mat_<float> matf;
 
 namespace slamhip {
 // The calling thread's context on device $SLAM_HIP_DEVICE (default 0), created on first use.
@@ -55,14 +57,36 @@ public:
         Match(const cv::Point2f& pos_, int iFeature_) : pos(pos_), iFeature(iFeature_) {}
     };
 
+    // The members of SLAM::CameraState (SLAM.hpp:26-46) this path reads: P = K [R | -R t] (3x4),
+    // KR = P(:, 0:3), t (3x1).  project is SLAM.hpp:150-158.
+    struct CameraState {
+        matf P, KR, t;
+        CameraState() {}
+        CameraState(const matf& P_, const matf& t_);      // KR is taken from P
+        matf project(const matf& p) const;
+    };
+
     // What Feature::project (feature.cpp:53-100) hands to the search: the warped template, its
-    // {0,1} mask and the predicted image point.  The warp itself stays on the CPU in the caller.
+    // {0,1} mask and the predicted image point.
     struct Projection {
         matb proj, projMask;
         cv::Point2f p2d;
     };
 
     struct Feature {
+        int iKalman = 0;
+        matb descriptor;
+        mutable matf B;        // 4x3 (feature.cpp:18-34); project writes p3d into column 2 (feature.cpp:61)
+
+        // feature.cpp:53-100: the matrix steps on the host, both warpPerspective calls on the device.
+        // Returns proj and fills mask / location; an empty Mat when the projection is empty or larger
+        // than 500 pixels (feature.cpp:56-59, 84-86).
+        matb project(const CameraState& state, const matf& p3d, matb& mask, cv::Rect& location) const;
+        // feature.cpp:102-173 with the reference's signature: project, then the coarse-to-fine walk, in
+        // one device pass (the projected template never visits the host).  disp is ignored.
+        cv::Point2i track(const ImagePyramid<byte>& pyramid, const CameraState& state, const matf& p3d,
+                          float threshold, int stride, float& response, cv::Mat* disp = nullptr) const;
+
         // feature.cpp:117-172 for an already projected feature: coarse-to-fine walk over the
         // pyramid levels on the device.  Returns Point2i(trackedPoint); (-1,-1) and response -1
         // when the projection is empty (feature.cpp:112-115).
@@ -79,6 +103,13 @@ public:
     // matching.cpp:230-269 after the projections: every feature of one frame in one batched launch;
     // keeps Match(pos, i) when response > threshold (matching.cpp:262-263).  stride 3 as matching.cpp:250.
     static void matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Projection>& features,
+                            std::vector<Match>& matches, float threshold = .95f, int stride = 3,
+                            std::vector<float>* responses = nullptr);
+
+    // matching.cpp:250-264 with the reference's inputs: feature i is projected with p3ds[i]
+    // (kalman.getPt3d(i), 3x1) and tracked, all features of the frame in one device pass.
+    static void matchPoints(const ImagePyramid<byte>& pyramid, const CameraState& state,
+                            const std::vector<Feature>& features, const std::vector<matf>& p3ds,
                             std::vector<Match>& matches, float threshold = .95f, int stride = 3,
                             std::vector<float>* responses = nullptr);
 

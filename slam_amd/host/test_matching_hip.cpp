@@ -4,6 +4,7 @@
 // each result is additionally required to equal the oracle's result bit for bit.
 //
 //   test_matching_hip [trials]      exit status 0 = every test passed
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -136,6 +137,119 @@ static bool test_pyramid_track_keypoints() {
     return true;
 }
 
+// Feature::project and Feature::track with the reference's signatures (feature.cpp:53-173) against the oracle:
+// a camera K [R | -R t] with a small rotation, planar features at depth z with slanted tangent directions.
+static bool test_project_track() {
+    const int w = 640, h = 480;
+    matb im0(h, w), im(h, w);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            im0(y, x) = (byte)(((x / 9) * 37 + (y / 7) * 91 + ((x * 7 + y * 13) % 23)) & 0xFF);
+            const int xs = x + 2, ys = y - 1;       // the current frame: the scene moved by (-2, +1)
+            im(y, x) = (byte)(((xs / 9) * 37 + (ys / 7) * 91 + ((xs * 7 + ys * 13) % 23)) & 0xFF);
+        }
+    const float f = 600.f, ca = std::cos(0.03f), sa = std::sin(0.03f);
+    const float K[3][3] = {{f, 0, 320}, {0, f, 240}, {0, 0, 1}}, R[3][3] = {{ca, 0, sa}, {0, 1, 0}, {-sa, 0, ca}};
+    const float t[3] = {0.02f, -0.01f, 0.03f};
+    matf P(3, 4), tm(3, 1);
+    for (int r = 0; r < 3; r++) {
+        float rt = 0;
+        for (int c = 0; c < 3; c++) rt += R[r][c] * t[c];
+        for (int c = 0; c < 4; c++) {
+            float acc = 0;
+            for (int k = 0; k < 3; k++) acc += K[r][k] * (c < 3 ? R[k][c] : 0.f);
+            P(r, c) = acc;
+        }
+        tm(r, 0) = t[r];
+        (void)rt;
+    }
+    for (int r = 0; r < 3; r++) {                    // P(:,3) = -K R t
+        float acc = 0;
+        for (int k = 0; k < 3; k++) acc += P(r, k) * t[k];
+        P(r, 3) = -acc;
+    }
+    const SLAM::CameraState state(P, tm);
+    std::vector<float> subs;
+    subs.push_back(1.f); subs.push_back(3.f);        // matching.cpp:243-246
+    ImagePyramid<byte> pyramid(im, subs);
+    uint8_t* lev[2]; int lw[2], lh[2];
+    std::vector<std::vector<uint8_t> > store(2);
+    for (int i = 0; i < 2; i++) {
+        so_pyramid_level_size(w, h, subs[i], &lw[i], &lh[i]);
+        store[i].resize((size_t)lw[i] * lh[i]);
+        lev[i] = store[i].data();
+    }
+    so_pyramid_build(im.data, w, h, (ptrdiff_t)im.step, 2, subs.data(), lev);
+    std::vector<SLAM::Feature> feats;
+    std::vector<matf> p3ds;
+    float Pf[12];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) Pf[r * 4 + c] = P(r, c);
+    for (int k = 0; k < 14; k++) {
+        const int cx = 60 + 38 * k, cy = 70 + 24 * k, half = 13;
+        const float z = 2.f + 0.3f * k, px = z / f;
+        SLAM::Feature ft;
+        ft.iKalman = k;
+        ft.descriptor = im0(Rect(cx - half, cy - half, 2 * half + 1, 2 * half + 1)).clone();
+        ft.B = matf(4, 3, 0.f);
+        ft.B(0, 0) = px * (1.f + 0.02f * k); ft.B(2, 0) = 0.15f * px;       // slanted in depth
+        ft.B(1, 1) = px * (1.f - 0.01f * k); ft.B(0, 1) = 0.05f * px; ft.B(2, 1) = -0.1f * px;
+        ft.B(3, 2) = 1.f;
+        // p3d such that K R (p3d - t) = z (cx, cy, 1): p3d = t + R^T K^-1 (cx, cy, 1) z
+        const float ray[3] = {(cx - 320.f) / f * z, (cy - 240.f) / f * z, z};
+        matf p3(3, 1);
+        for (int r = 0; r < 3; r++) p3(r, 0) = t[r] + R[0][r] * ray[0] + R[1][r] * ray[1] + R[2][r] * ray[2];
+        feats.push_back(ft);
+        p3ds.push_back(p3);
+    }
+    feats.push_back(SLAM::Feature());                 // no descriptor: empty projection (feature.cpp:56-59)
+    feats.back().B = matf(4, 3, 0.f);
+    p3ds.push_back(p3ds[0]);
+    std::vector<SLAM::Match> matches;
+    std::vector<float> resp;
+    SLAM::matchPoints(pyramid, state, feats, p3ds, matches, 0.9f, 3, &resp);
+    size_t nm = 0, tracked = 0;
+    for (size_t k = 0; k < feats.size(); k++) {
+        const SLAM::Feature& ft = feats[k];
+        matb mask; Rect loc;
+        const matb proj = ft.project(state, p3ds[k], mask, loc);
+        float r1 = 0;
+        const Point2i one = ft.track(pyramid, state, p3ds[k], 0.9f, 3, r1);
+        if (ft.descriptor.empty()) {
+            if (!proj.empty() || one.x != -1 || one.y != -1 || r1 != -1.f || resp[k] != -1.f) { printf("empty feature %zu\n", k); return false; }
+            continue;
+        }
+        float Bf[12], pf[3];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 3; c++) Bf[r * 3 + c] = ft.B(r, c);
+        for (int r = 0; r < 3; r++) pf[r] = p3ds[k](r, 0);
+        std::vector<uint8_t> op(250000), om(250000);
+        so_projection sp;
+        so_project(ft.descriptor.data, ft.descriptor.cols, ft.descriptor.rows, (ptrdiff_t)ft.descriptor.step, Pf, Bf, pf, op.data(), om.data(), op.size(), &sp);
+        if (!sp.valid || proj.cols != sp.w || proj.rows != sp.h || loc.x != sp.x || loc.y != sp.y || loc.width != sp.w || loc.height != sp.h) {
+            printf("project %zu: location (%d,%d,%d,%d) oracle (%d,%d,%d,%d) valid %d\n", k, loc.x, loc.y, loc.width, loc.height, sp.x, sp.y, sp.w, sp.h, sp.valid);
+            return false;
+        }
+        for (int y = 0; y < sp.h; y++)
+            if (std::memcmp(proj.ptr(y), op.data() + (size_t)y * sp.w, sp.w) != 0 || std::memcmp(mask.ptr(y), om.data() + (size_t)y * sp.w, sp.w) != 0) {
+                printf("project %zu: row %d differs\n", k, y);
+                return false;
+            }
+        const matf p2d = state.project(p3ds[k]);
+        so_track_out o;
+        so_track(lev, lw, lh, subs.data(), 2, op.data(), om.data(), sp.w, sp.h, p2d(0, 0), p2d(1, 0), 0.9f, 3, &o);
+        if (one.x != o.x || one.y != o.y || std::memcmp(&r1, &o.response, 4) != 0 || std::memcmp(&resp[k], &o.response, 4) != 0) {
+            printf("track %zu: HIP (%d,%d,%.9g) oracle (%d,%d,%.9g)\n", k, one.x, one.y, r1, o.x, o.y, o.response);
+            return false;
+        }
+        tracked += o.levels_run == 2;
+        if (o.response > 0.9f) {
+            if (nm >= matches.size() || matches[nm].iFeature != (int)k || matches[nm].pos.x != (float)o.x || matches[nm].pos.y != (float)o.y) return false;
+            nm++;
+        }
+    }
+    if (nm != matches.size() || tracked < 7) { printf("matches %zu of %zu, %zu walked both levels\n", nm, matches.size(), tracked); return false; }
+    return true;
+}
+
 int main(int argc, char* argv[]) {
     const int nTrials = argc > 1 ? std::atoi(argv[1]) : 100;
     int failed = 0;
@@ -147,6 +261,7 @@ int main(int argc, char* argv[]) {
         DO_TEST("test_matchingPatch", test_matching0(false, true, nTrials));
         DO_TEST("test_matchingPatchArea", test_matching0(true, true, nTrials));
         DO_TEST("test_pyramid_track_keypoints", test_pyramid_track_keypoints());
+        DO_TEST("test_project_track", test_project_track());
     } catch (const std::exception& e) {
         printf("exception: %s\n", e.what());
         return 2;

@@ -81,3 +81,48 @@ def ellipse_mask(aw, ah, a, b, theta):
     u = (x - xc) * c + (y - yc) * s
     v = -(x - xc) * s + (y - yc) * c
     return ((u / max(a, 0.5)) ** 2 + (v / max(b, 0.5)) ** 2 <= 1.0).astype(np.uint8)
+
+
+def camera(w, h, rng, tilt=0.05):
+    """A 3x4 projection matrix P = K [R | -R t] (float32) of a camera looking down +z with a small random
+    rotation and offset: the `state.P` that Feature::project multiplies with B (feature.cpp:62)."""
+    f = float(rng.uniform(0.8, 1.2)) * w
+    K = np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1.0]])
+    ax, ay, az = rng.uniform(-tilt, tilt, 3)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx
+    t = rng.uniform(-0.05, 0.05, 3)
+    P = K @ np.hstack([R, (-R @ t)[:, None]])
+    return P.astype(np.float32)
+
+
+def plane_feature(P, cx, cy, rng, depth=(2.0, 6.0), slant=0.4, scale=(0.8, 1.25)):
+    """A planar feature seen at image point (cx, cy): returns (B, p3d, p2d) with B the 4x3 matrix of
+    SLAM::Feature (feature.cpp:29-33: two in-plane directions scaled to about one descriptor pixel per
+    image pixel, last row 0 0 1; column 2 is filled with p3d by project) and p2d = P [p3d; 1]
+    dehomogenised (SLAM.hpp:150-158)."""
+    P = np.asarray(P, np.float64)
+    M, c = P[:, :3], P[:, 3]
+    z = float(rng.uniform(*depth))
+    ray = np.linalg.solve(M, np.array([cx, cy, 1.0]))
+    p3d = np.linalg.solve(M, np.array([cx, cy, 1.0]) * z - c)       # M p3d + c = z (cx, cy, 1)
+    n = ray / np.linalg.norm(ray) + rng.uniform(-slant, slant, 3)
+    n /= np.linalg.norm(n)
+    u = np.cross(n, [0.0, 1.0, 0.0]); u /= np.linalg.norm(u)
+    v = np.cross(n, u); v /= np.linalg.norm(v)
+    if (M @ u)[0] < 0:
+        u = -u
+    if (M @ v)[1] < 0:
+        v = -v
+    pix = z / np.linalg.norm(M[0])                                   # scene length of one pixel at depth z
+    B = np.zeros((4, 3))
+    B[:3, 0] = u * pix * float(rng.uniform(*scale))
+    B[:3, 1] = v * pix * float(rng.uniform(*scale))
+    B[3, 2] = 1.0
+    B = B.astype(np.float32)
+    p3 = p3d.astype(np.float32)
+    a = P.astype(np.float32).astype(np.float64) @ np.append(p3.astype(np.float64), 1.0)
+    p2d = (np.float32(a[0] / a[2]), np.float32(a[1] / a[2]))
+    return B, p3, p2d

@@ -42,6 +42,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.KeyPoint) == 12
     assert C.sizeof(capi.DescJob) == 32
     assert C.sizeof(capi.DescResult) == 20
+    assert C.sizeof(capi.WarpJob) == 80
 
 
 def test_null_context_is_rejected_without_touching_a_gpu():
