@@ -289,6 +289,53 @@ int slam_hip_project_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_
                                  size_t desc_bytes, slam_track_result* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * Line features — the image work of SLAM::LineFeature::track (SLAM.hpp:68-80, lineFeature.cpp:22-166)
+ * as called by SLAM::matchLines (matching.cpp:271-310).  The cone bins are projected by the caller
+ * (lineFeature.cpp:41-84; the cone stays on the CPU); what runs here is the area mask of filled discs
+ * (lineFeature.cpp:86-96) and the searches (lineFeature.cpp:120-165).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct slam_disc_job {
+    int64_t mask_off;                 /* mask in the blob, pitch w; every byte of it is written (0 or 255) */
+    int32_t w, h;                     /* areaRect.width, areaRect.height */
+    int32_t circle_begin, circle_count;   /* this job's (x, y, radius) triples in the circle table */
+} slam_disc_job;
+
+/* matb areaMask(h, w, 0) followed by cv::circle(areaMask, pt, radius, Scalar(255), -1) per triple
+ * (lineFeature.cpp:87-96); centres are relative to the mask.  d_circles holds ncircles int32 triples.
+ * d_status (optional) receives 0 / SLAM_HIP_EINVAL per job (negative radius, ranges outside the
+ * tables).  max_pixels: largest w*h of the batch if known, else 0.  Asynchronous, allocates nothing. */
+int slam_hip_disc_masks_d(slam_ctx* ctx, const int32_t* d_circles, int ncircles, const slam_disc_job* d_jobs,
+                          int njobs, uint8_t* d_blob, size_t blob_bytes, int32_t* d_status, int max_pixels);
+
+typedef struct slam_line_job {
+    int64_t desc_off;                 /* LineFeature::descriptor in the blob, pitch dw */
+    int64_t amask_off;                /* areaMask of the coarsest level in the blob, pitch aw (tested for non-zero) */
+    int32_t frame;
+    int32_t dw, dh;
+    int32_t ax, ay, aw, ah;           /* areaRect on the coarsest level (lineFeature.cpp:86) */
+    float   threshold;
+    int32_t stride;
+    int32_t reserved;
+} slam_line_job;
+
+/* The searches of LineFeature::track: result (x, y) = trackedPoint, response, levels_run; sub-pixel
+ * offset of the last level searched.  A level whose resized descriptor would be empty gives (-1,-1),
+ * response -1 (cv::resize would throw there).  The area-size cap of lineFeature.cpp:81-84 is the
+ * caller's (it precedes the mask). */
+int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* d_jobs,
+                                int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                                slam_track_result* d_out);
+int slam_hip_line_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* jobs, int njobs,
+                              const uint8_t* blob, size_t blob_bytes, slam_track_result* out);
+/* The per-frame loop of SLAM::matchLines (matching.cpp:279-292), host tables: job i's area mask is
+ * rasterised on the device from circle triples [circle_begin[i], circle_begin[i+1]) (centres relative
+ * to the job's area rectangle; circle_begin has njobs+1 entries) and searched there; jobs[i].amask_off
+ * is assigned here, jobs[i].desc_off points into desc_blob. */
+int slam_hip_match_lines_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* jobs, int njobs,
+                               const int32_t* circles, int ncircles, const int32_t* circle_begin,
+                               const uint8_t* desc_blob, size_t desc_bytes, slam_track_result* out);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (used by the parity tests; no reference counterpart).
  * ------------------------------------------------------------------------------------------- */
 /* Evaluates the two score formulas of matching.cpp on the device for n triples of exact integer

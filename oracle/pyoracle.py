@@ -98,6 +98,12 @@ def lib():
         L.so_warp_perspective_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_int,
                                              C.c_void_p, C.c_int, C.c_int, C.c_ssize_t]
         L.so_warp_perspective_u8.restype = C.c_int
+        L.so_disc_mask.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.so_disc_mask.restype = C.c_int
+        L.so_line_track.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_float, C.c_int, C.POINTER(TrackOut)]
+        L.so_line_track.restype = C.c_int
         L.so_proptest_srand.argtypes = [C.c_uint]
         L.so_proptest_srand.restype = None
         L.so_proptest_next.argtypes = [C.c_int, C.c_int, C.POINTER(PropCase)]
@@ -291,6 +297,34 @@ def project(descriptor, P, B, p3d):
         return np.zeros((0, 0), np.uint8), np.zeros((0, 0), np.uint8), s["loc"]
     _, _, w, h = s["loc"]
     return warp_perspective(d, s["m"], w, h, False), warp_perspective(np.ones_like(d), s["m"], w, h, True), s["loc"]
+
+
+def disc_mask(w, h, circles):
+    """lineFeature.cpp:86-96: zero mask with one filled cv::circle (value 255) per (x, y, radius)."""
+    c = np.ascontiguousarray(circles, np.int32).reshape(-1, 3)
+    out = np.empty((h, w), np.uint8)
+    if lib().so_disc_mask(w, h, c.ctypes.data, len(c), out.ctypes.data) != 0:
+        raise ValueError("so_disc_mask: bad arguments")
+    return out
+
+
+def line_track(levels, subs, descriptor, area, area_mask, threshold, stride):
+    """The searches of LineFeature::track (lineFeature.cpp:120-165); area = (x, y, w, h) on the coarsest level."""
+    levels = [_u8(l) for l in levels]
+    n = len(levels)
+    ptrs = (C.c_void_p * n)(*[l.ctypes.data for l in levels])
+    lw = (C.c_int * n)(*[l.shape[1] for l in levels])
+    lh = (C.c_int * n)(*[l.shape[0] for l in levels])
+    fs = (C.c_float * n)(*[float(s) for s in subs])
+    d = _u8(descriptor)
+    am = _u8(area_mask)
+    assert am.shape == (area[3], area[2])
+    out = TrackOut()
+    rc = lib().so_line_track(ptrs, lw, lh, fs, n, d.ctypes.data, d.shape[1], d.shape[0], area[0], area[1], area[2], area[3],
+                             am.ctypes.data, C.c_float(threshold), stride, C.byref(out))
+    if rc != 0:
+        raise ValueError("so_line_track: bad arguments")
+    return dict(x=out.x, y=out.y, response=out.response, dx=out.dx, dy=out.dy, levels_run=out.levels_run)
 
 
 class PropTest:

@@ -382,6 +382,108 @@ int so_track(uint8_t* const* levels, const int* lw, const int* lh, const float* 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* LineFeature::track (lineFeature.cpp:86-165): the disc mask and the level walk              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* cv::circle(img, center, radius, Scalar(255), -1) on CV_8UC1: thickness < 0 and line type 8 select
+ * OpenCV 2.4's Circle(img, center, radius, color, fill = 1) (drawing.cpp), the midpoint walk
+ * (dx, dy) from (radius, 0) with err = dx^2 + dy^2 - radius^2 that fills the rows center.y +- dy over
+ * center.x +- dx and the rows center.y +- dx over center.x +- dy, clipped to the image. */
+static void hline255(uint8_t* row, int xl, int xr, int w) {
+    if (xl < 0) xl = 0;
+    if (xr > w - 1) xr = w - 1;
+    for (int x = xl; x <= xr; x++) row[x] = 255;
+}
+
+static void cv_circle_filled(uint8_t* img, int w, int h, ptrdiff_t pitch, int cx, int cy, int radius) {
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        const int y11 = cy - dy, y12 = cy + dy, y21 = cy - dx, y22 = cy + dx;
+        const int x11 = cx - dx, x12 = cx + dx, x21 = cx - dy, x22 = cx + dy;
+        if (x11 < w && x12 >= 0 && y21 < h && y22 >= 0) {
+            if ((unsigned)y11 < (unsigned)h) hline255(img + (ptrdiff_t)y11 * pitch, x11, x12, w);
+            if ((unsigned)y12 < (unsigned)h) hline255(img + (ptrdiff_t)y12 * pitch, x11, x12, w);
+            if (x21 < w && x22 >= 0) {
+                if ((unsigned)y21 < (unsigned)h) hline255(img + (ptrdiff_t)y21 * pitch, x21, x22, w);
+                if ((unsigned)y22 < (unsigned)h) hline255(img + (ptrdiff_t)y22 * pitch, x21, x22, w);
+            }
+        }
+        dy++;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+int so_disc_mask(int w, int h, const int* circles, int ncircles, uint8_t* mask) {
+    if (w <= 0 || h <= 0 || ncircles < 0) return -1;
+    memset(mask, 0, (size_t)w * h);                           /* lineFeature.cpp:87 */
+    for (int i = 0; i < ncircles; i++) {                      /* lineFeature.cpp:88-96 */
+        if (circles[3 * i + 2] < 0) return -1;                /* cv::circle asserts radius >= 0 */
+        cv_circle_filled(mask, w, h, w, circles[3 * i], circles[3 * i + 1], circles[3 * i + 2]);
+    }
+    return 0;
+}
+
+int so_line_track(uint8_t* const* levels, const int* lw, const int* lh, const float* subs, int nlev,
+                  const uint8_t* descr, int dw, int dh, int ax, int ay, int aw, int ah,
+                  const uint8_t* area_mask, float threshold, int stride, so_track_out* out) {
+    memset(out, 0, sizeof(*out));
+    if (nlev < 1 || stride < 1 || dw <= 0 || dh <= 0 || aw <= 0 || ah <= 0) return -1;
+    uint8_t* tbuf = (uint8_t*)malloc((size_t)dw * dh * 4 + 16);
+    if (!tbuf) return -1;
+    const float areaRes = 1.f / subs[nlev - 1];               /* lineFeature.cpp:30 */
+    const float desch = (float)dh, descw = (float)dw;         /* lineFeature.cpp:122 */
+    /* lineFeature.cpp:124: Size(round(descw*areaRes), round(desch*areaRes)) */
+    int tw = (int)round((double)(descw * areaRes)), th = (int)round((double)(desch * areaRes));
+    int tpx = -1, tpy = -1;
+    float response = -1.f;
+    if (tw <= 0 || th <= 0 || (size_t)tw * th > (size_t)dw * dh * 4) goto fail;   /* cv::resize would throw: reported as a failure */
+    so_resize_u8_linear(descr, dw, dh, dw, tbuf, tw, th, tw);
+    {
+        so_match_out m;                                       /* lineFeature.cpp:125-127 */
+        so_match_feature_in_area(levels[nlev - 1], lw[nlev - 1], lh[nlev - 1], lw[nlev - 1], tbuf, tw, th, tw, NULL, 0,
+                                 ax, ay, aw, ah, area_mask, aw, stride, 0, NULL, &m);
+        response = m.response;
+        out->levels_run = 1; out->dx = m.dx; out->dy = m.dy;
+        const double inv = 1. / (double)areaRes;              /* lineFeature.cpp:130: Point2i *= double rounds (cvRound) */
+        tpx = cv_round((double)m.x * inv);
+        tpy = cv_round((double)m.y * inv);
+    }
+    if ((double)response > (double)threshold * 0.67) {        /* lineFeature.cpp:144 */
+        for (int iSub = nlev - 2; iSub >= 0; --iSub) {
+            const float lastsub = subs[iSub + 1], sub = subs[iSub];
+            const int laststride = stride, newstride = (iSub == 0) ? 1 : stride;
+            const int searchRad = (int)(sub / lastsub * (float)laststride / (float)newstride);   /* lineFeature.cpp:150 */
+            /* lineFeature.cpp:151-152: Rect(int/float - int, ...) converts the float expressions to int by truncation */
+            const int rx = (int)((float)tpx / sub - (float)searchRad), ry = (int)((float)tpy / sub - (float)searchRad);
+            const int rs = 2 * searchRad + 1;
+            tw = (int)(descw / sub); th = (int)(desch / sub); /* lineFeature.cpp:153 */
+            if (tw <= 0 || th <= 0) goto fail;
+            so_resize_u8_linear(descr, dw, dh, dw, tbuf, tw, th, tw);
+            so_match_out m;                                   /* lineFeature.cpp:154-156 */
+            so_match_feature_in_area(levels[iSub], lw[iSub], lh[iSub], lw[iSub], tbuf, tw, th, tw, NULL, 0,
+                                     rx, ry, rs, rs, NULL, 0, newstride, 0, NULL, &m);
+            response = m.response;
+            out->levels_run++; out->dx = m.dx; out->dy = m.dy;
+            tpx = cv_round((double)((float)m.x * sub));       /* lineFeature.cpp:157: Point2i *= float rounds (cvRound) */
+            tpy = cv_round((double)((float)m.y * sub));
+            if ((double)response < (double)threshold * 0.67) break;   /* lineFeature.cpp:158-159 */
+        }
+    }
+    free(tbuf);
+    out->x = tpx; out->y = tpy; out->response = response;
+    return 0;
+fail:
+    free(tbuf);
+    out->x = -1; out->y = -1; out->response = -1.f; out->dx = out->dy = 0.f;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* cv::FAST, 16-pixel ring, 9 contiguous (new_point.cpp:120)                                  */
 /* ------------------------------------------------------------------------------------------ */
 

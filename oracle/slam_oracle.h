@@ -14,6 +14,7 @@
  *   new_point.cpp:137-155     SLAM::addNewLines selection  -> so_select_new_points
  *   feature.cpp:36-51         Feature::newDescriptor crop  -> so_extract_descriptor
  *   feature.cpp:53-100        SLAM::Feature::project       -> so_project_setup, so_warp_perspective_u8
+ *   lineFeature.cpp:86-165    LineFeature::track searches  -> so_disc_mask, so_line_track
  *   tests/test_matching.cpp   property test generator      -> so_proptest_*
  *
  * The arithmetic of cv::resize, cv::matchTemplate, cv::norm / Mat::dot / Mat::mul,
@@ -82,6 +83,18 @@ typedef struct so_track_out {
 int so_track(uint8_t* const* levels, const int* lw, const int* lh, const float* subs, int nlev,
              const uint8_t* proj, const uint8_t* proj_mask, int projw, int projh,
              float px, float py, float threshold, int stride, so_track_out* out);
+
+/* lineFeature.cpp:86-96: the area mask of LineFeature::track, zero-filled w x h with one filled
+ * cv::circle of value 255 per (x, y, radius) triple.  Returns 0 / -1. */
+int so_disc_mask(int w, int h, const int* circles, int ncircles, uint8_t* mask);
+
+/* lineFeature.cpp:120-165: the searches of LineFeature::track given the coarsest-level area
+ * rectangle and its mask (lineFeature.cpp:86-96): descriptor resized per level, coarsest level
+ * searched without a patch mask inside the area mask, finer levels in (2*searchRad+1)^2 windows.
+ * A level whose resized descriptor would be empty is reported as (-1,-1), response -1. */
+int so_line_track(uint8_t* const* levels, const int* lw, const int* lh, const float* subs, int nlev,
+                  const uint8_t* descr, int dw, int dh, int ax, int ay, int aw, int ah,
+                  const uint8_t* area_mask, float threshold, int stride, so_track_out* out);
 
 typedef struct so_keypoint {
     float x, y;       /* KeyPoint::pt */

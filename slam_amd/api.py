@@ -56,6 +56,31 @@ class Context:
         self.close()
 
 
+class DeviceBuffer:
+    """Device memory through the ABI's own helpers (slam_hip_malloc / memcpy), for callers of the `_d` entry points
+    that hold no HIP runtime of their own.  Created from a host array (copied) or as nbytes filled with `fill`."""
+
+    def __init__(self, ctx, host=None, nbytes=None, fill=0):
+        self.ctx = ctx
+        if host is None:
+            host = np.full(max(int(nbytes), 1), fill, np.uint8)
+        h = np.ascontiguousarray(host)
+        self.nbytes = int(h.nbytes)
+        self.ptr = C.c_void_p()
+        check(ctx.handle, lib().slam_hip_malloc(ctx.handle, max(self.nbytes, 16), C.byref(self.ptr)))
+        check(ctx.handle, lib().slam_hip_memcpy_h2d(ctx.handle, self.ptr, h.ctypes.data, self.nbytes))
+
+    def get(self, dtype=np.uint8):
+        out = np.zeros(self.nbytes, np.uint8)
+        check(self.ctx.handle, lib().slam_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            lib().slam_hip_free(self.ctx.handle, self.ptr)
+            self.ptr = C.c_void_p()
+
+
 class Blob:
     """Packs patches and masks (rows contiguous) and hands out their byte offsets."""
 
@@ -340,6 +365,61 @@ def project_track_batch(ctx, pyr, jobs):
     b = blob.bytes()
     res = (TrackResult * max(n, 1))()
     check(ctx.handle, lib().slam_hip_project_track_batch(ctx.handle, pyr.handle, wj, tj, n, b.ctypes.data, b.size, res))
+    return [dict(x=r.x, y=r.y, response=r.response, dx=r.dx, dy=r.dy, levels_run=r.levels_run, status=r.status)
+            for r in res[:n]]
+
+
+def line_track_batch(ctx, pyr, jobs):
+    """The searches of SLAM::LineFeature::track (lineFeature.cpp:120-165).  jobs: list of dicts(frame, descriptor,
+    area=(x, y, w, h) on the coarsest level, area_mask, threshold, stride)."""
+    n = len(jobs)
+    blob = Blob()
+    arr = (capi.LineJob * max(n, 1))()
+    for i, j in enumerate(jobs):
+        d, am = _u8(j["descriptor"]), _u8(j["area_mask"])
+        a = arr[i]
+        a.frame = j.get("frame", 0)
+        a.dh, a.dw = d.shape
+        a.ax, a.ay, a.aw, a.ah = j["area"]
+        if am.shape != (a.ah, a.aw):
+            raise ValueError("area mask shape")
+        a.desc_off = blob.add(d)
+        a.amask_off = blob.add(am)
+        a.threshold = float(j["threshold"])
+        a.stride = int(j["stride"])
+    b = blob.bytes()
+    res = (TrackResult * max(n, 1))()
+    check(ctx.handle, lib().slam_hip_line_track_batch(ctx.handle, pyr.handle, arr, n, b.ctypes.data, b.size, res))
+    return [dict(x=r.x, y=r.y, response=r.response, dx=r.dx, dy=r.dy, levels_run=r.levels_run, status=r.status)
+            for r in res[:n]]
+
+
+def match_lines_batch(ctx, pyr, jobs):
+    """SLAM::matchLines' image work (matching.cpp:279-292): like line_track_batch, but each job carries `circles`
+    ([k,3] x, y, radius relative to its area) instead of an area mask; the masks are drawn on the device."""
+    n = len(jobs)
+    blob = Blob()
+    arr = (capi.LineJob * max(n, 1))()
+    begin = np.zeros(n + 1, np.int32)
+    circ = []
+    for i, j in enumerate(jobs):
+        d = _u8(j["descriptor"])
+        a = arr[i]
+        a.frame = j.get("frame", 0)
+        a.dh, a.dw = d.shape
+        a.ax, a.ay, a.aw, a.ah = j["area"]
+        a.desc_off = blob.add(d)
+        a.amask_off = -1
+        a.threshold = float(j["threshold"])
+        a.stride = int(j["stride"])
+        c = np.ascontiguousarray(j["circles"], np.int32).reshape(-1, 3)
+        circ.append(c)
+        begin[i + 1] = begin[i] + len(c)
+    allc = np.concatenate(circ) if circ else np.zeros((0, 3), np.int32)
+    b = blob.bytes()
+    res = (TrackResult * max(n, 1))()
+    check(ctx.handle, lib().slam_hip_match_lines_batch(ctx.handle, pyr.handle, arr, n, allc.ctypes.data if len(allc) else None,
+                                                       len(allc), begin.ctypes.data, b.ctypes.data, b.size, res))
     return [dict(x=r.x, y=r.y, response=r.response, dx=r.dx, dy=r.dy, levels_run=r.levels_run, status=r.status)
             for r in res[:n]]
 

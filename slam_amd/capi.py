@@ -67,6 +67,16 @@ class WarpJob(C.Structure):
                 ("ow", C.c_int32), ("oh", C.c_int32), ("m", C.c_float * 9), ("reserved", C.c_int32)]
 
 
+class DiscJob(C.Structure):
+    _fields_ = [("mask_off", C.c_int64), ("w", C.c_int32), ("h", C.c_int32), ("circle_begin", C.c_int32), ("circle_count", C.c_int32)]
+
+
+class LineJob(C.Structure):
+    _fields_ = [("desc_off", C.c_int64), ("amask_off", C.c_int64), ("frame", C.c_int32), ("dw", C.c_int32), ("dh", C.c_int32),
+                ("ax", C.c_int32), ("ay", C.c_int32), ("aw", C.c_int32), ("ah", C.c_int32), ("threshold", C.c_float),
+                ("stride", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/slam_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -112,6 +122,10 @@ SIGNATURES = {
     "slam_hip_warp_batch_d": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, _P, C.c_size_t, _P, C.c_int]),
     "slam_hip_project": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, _P, _P, _P, _P, C.c_size_t, _P, C.POINTER(C.c_int32)]),
     "slam_hip_project_track_batch": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "slam_hip_disc_masks_d": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, C.c_size_t, _P, C.c_int]),
+    "slam_hip_line_track_batch_d": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "slam_hip_line_track_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "slam_hip_match_lines_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "slam_hip_debug_score_formulas": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "slam_hip_debug_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int, C.c_size_t]),
     "slam_hip_version": (C.c_char_p, []),

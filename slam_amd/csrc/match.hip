@@ -321,6 +321,102 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
     }
 }
 
+// The searches of SLAM::LineFeature::track (lineFeature.cpp:120-165) for one line feature: the
+// descriptor resized to the coarsest level and searched without a patch mask inside the area mask
+// (lineFeature.cpp:124-127), then, while the response stays above 0.67*threshold, each finer level in
+// a (2*searchRad+1)^2 window around the previous result (lineFeature.cpp:144-160).
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void line_track_kernel(slam_pyr_dev pyr, const slam_line_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_bytes,
+                                                        slam_track_result* __restrict__ out, int force_direct, int lds_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const LdsPlan plan = make_lds_plan(lds_total);
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_line_job job = jobs[j];
+    const int tid = threadIdx.x;
+    const bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.dw >= 1 && job.dh >= 1 && job.dw <= SLAM_MAX_TMPL &&
+                    job.dh <= SLAM_MAX_TMPL && job.stride >= 1 && job.stride <= 1024 && job.aw >= 1 && job.ah >= 1 &&
+                    job.aw <= (1 << 12) && job.ah <= (1 << 12) &&
+                    job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28) &&
+                    span_ok(job.desc_off, (long long)job.dw * job.dh, blob_bytes) &&
+                    span_ok(job.amask_off, (long long)job.aw * job.ah, blob_bytes) && job.threshold == job.threshold;
+    if (!ok) {
+        if (tid == 0) { slam_track_result r = {-1, -1, -1.f, 0.f, 0.f, 0, SLAM_HIP_EINVAL}; out[j] = r; }
+        return;
+    }
+    Tmpl t;
+    t.patch = blob + job.desc_off; t.mask = nullptr;
+    t.srcw = job.dw; t.srch = job.dh;
+    t.limit = blob + blob_bytes;
+    const double keep_above = __dmul_rn((double)job.threshold, 0.67);   // lineFeature.cpp:144,158
+    const float descw = (float)job.dw, desch = (float)job.dh;           // lineFeature.cpp:122
+
+    int tpx = -1, tpy = -1, levels_run = 0;
+    float response = -1.f, sdx = 0.f, sdy = 0.f;
+    bool failed = false;
+    float lastsub = 1.f;
+    for (int i = pyr.nlev - 1; i >= 0 && !failed; --i) {
+        float sub = 1.f; int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
+#pragma unroll
+        for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++)
+            if (l == i) { sub = pyr.lev[l].sub; lw = pyr.lev[l].w; lh = pyr.lev[l].h; lp = pyr.lev[l].pitch; ls = pyr.lev[l].frame_stride; ld = pyr.lev[l].data; }
+        const bool coarsest = i == pyr.nlev - 1;
+        int ax, ay, aw, ah, stride;
+        const uint8_t* am = nullptr;
+        float areaRes = 1.f;
+        if (coarsest) {
+            areaRes = __fdiv_rn(1.f, sub);                                         // lineFeature.cpp:30
+            t.tw = (int)round((double)__fmul_rn(descw, areaRes));                  // lineFeature.cpp:124
+            t.th = (int)round((double)__fmul_rn(desch, areaRes));
+            ax = job.ax; ay = job.ay; aw = job.aw; ah = job.ah; am = blob + job.amask_off; stride = job.stride;
+        } else {
+            stride = (i == 0) ? 1 : job.stride;                                    // lineFeature.cpp:148-150
+            const int searchRad = (int)__fdiv_rn(__fmul_rn(__fdiv_rn(sub, lastsub), (float)job.stride), (float)stride);
+            ax = (int)__fsub_rn(__fdiv_rn((float)tpx, sub), (float)searchRad);    // lineFeature.cpp:151-152
+            ay = (int)__fsub_rn(__fdiv_rn((float)tpy, sub), (float)searchRad);
+            aw = ah = 2 * searchRad + 1;
+            t.tw = (int)__fdiv_rn(descw, sub);                                     // lineFeature.cpp:153
+            t.th = (int)__fdiv_rn(desch, sub);
+        }
+        ax = __builtin_amdgcn_readfirstlane(ax); ay = __builtin_amdgcn_readfirstlane(ay);
+        t.tw = __builtin_amdgcn_readfirstlane(t.tw); t.th = __builtin_amdgcn_readfirstlane(t.th);
+        if (t.tw <= 0 || t.th <= 0 || t.tw > 2 * SLAM_MAX_TMPL || t.th > 2 * SLAM_MAX_TMPL || aw < 1) { failed = true; break; }
+        t.resized = !(t.tw == job.dw && t.th == job.dh);      // cv::resize to the same size copies the image
+        t.scale_x = 1.0; t.scale_y = 1.0;
+        if (t.resized) { t.scale_x = resize_scale(job.dw, t.tw); t.scale_y = resize_scale(job.dh, t.th); }
+        const Geo g = make_geo(ld + (long long)job.frame * ls, lw, lh, lp, t.tw, t.th, ax, ay, aw, ah, am, stride, false, false);
+        int mx = 0, my = 0;
+        sdx = 0.f; sdy = 0.f;
+        levels_run++;
+        if (g.reject) response = -1.f;                        // matching.cpp:26-30
+        else {
+            const CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, true, 0.0);
+            mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
+        }
+        if (coarsest) {                                       // lineFeature.cpp:130: Point2i *= double rounds to nearest even
+            const double inv = __ddiv_rn(1.0, (double)areaRes);
+            tpx = __double2int_rn(__dmul_rn((double)mx, inv));
+            tpy = __double2int_rn(__dmul_rn((double)my, inv));
+            if (!((double)response > keep_above)) break;      // lineFeature.cpp:144
+        } else {                                              // lineFeature.cpp:157: Point2i *= float
+            tpx = __float2int_rn(__fmul_rn((float)mx, sub));
+            tpy = __float2int_rn(__fmul_rn((float)my, sub));
+            if ((double)response < keep_above) break;         // lineFeature.cpp:158-159
+        }
+        lastsub = sub;
+    }
+    if (tid == 0) {
+        slam_track_result r;
+        if (failed) { r.x = -1; r.y = -1; r.response = -1.f; r.dx = 0.f; r.dy = 0.f; }
+        else { r.x = tpx; r.y = tpy; r.response = response; r.dx = sdx; r.dy = sdy; }
+        r.levels_run = levels_run;
+        r.status = SLAM_HIP_OK;
+        out[j] = r;
+    }
+}
+
 __global__ void score_formula_kernel(const unsigned long long* cc, const unsigned long long* si,
                                      const unsigned long long* sp, int n, float* f32o, float* mto) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,6 +580,46 @@ extern "C" int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const sl
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[1], blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = slam_hip_track_batch_d(ctx, pyr, (const slam_track_job*)ctx->d_stage[0], njobs,
                                 (const uint8_t*)ctx->d_stage[1], blob_bytes, (slam_track_result*)ctx->d_stage[2]);
+    if (rc != SLAM_HIP_OK) return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_stage[2], rb, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* d_jobs,
+                                           int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                                           slam_track_result* d_out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!d_jobs || !d_blob || !d_out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "line_track_batch: null table or negative count");
+    int rc = check_pyr(ctx, pyr, "line_track_batch");
+    if (rc != SLAM_HIP_OK) return rc;
+    if (njobs == 0) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(line_track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
+                       ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
+                       ctx->force_direct, ctx->match_lds_bytes);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_line_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* jobs, int njobs,
+                                         const uint8_t* blob, size_t blob_bytes, slam_track_result* out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!jobs || !blob || !out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "line_track_batch: null table or negative count");
+    int rc = check_pyr(ctx, pyr, "line_track_batch");
+    if (rc != SLAM_HIP_OK) return rc;
+    if (njobs == 0) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t jb = sizeof(slam_line_job) * (size_t)njobs, rb = sizeof(slam_track_result) * (size_t)njobs;
+    if ((rc = slam_stage_reserve(ctx, 0, jb)) || (rc = slam_stage_reserve(ctx, 1, blob_bytes + 16)) ||
+        (rc = slam_stage_reserve(ctx, 2, rb)))
+        return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[0], jobs, jb, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[1], blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = slam_hip_line_track_batch_d(ctx, pyr, (const slam_line_job*)ctx->d_stage[0], njobs,
+                                     (const uint8_t*)ctx->d_stage[1], blob_bytes, (slam_track_result*)ctx->d_stage[2]);
     if (rc != SLAM_HIP_OK) return rc;
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_stage[2], rb, hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -268,3 +268,126 @@ extern "C" int slam_hip_project(slam_ctx* ctx, const uint8_t* descr, int dw, int
     if (st != SLAM_HIP_OK) return slam_set_error(ctx, st, "project: job rejected by the device");
     return SLAM_HIP_OK;
 }
+
+// ---- area mask of LineFeature::track (lineFeature.cpp:86-96) ----------------------------------
+namespace {
+
+// One workgroup per (job, slice of the mask).  cv::circle with thickness -1 walks the midpoint
+// circle (dx, dy) keeping err = dx^2 + dy^2 - r^2 <= 0 and fills the rows cy +- dy over cx +- dx and
+// cy +- dx over cx +- dy: the filled set is exactly { (x, y) : (x-cx)^2 + (y-cy)^2 <= r^2 }, so a
+// pixel is 255 when it lies in one of the job's discs and 0 otherwise.
+__global__ __launch_bounds__(WARP_WG) void disc_mask_kernel(const int32_t* __restrict__ circles, int ncircles,
+                                                            const slam_disc_job* __restrict__ jobs, int njobs,
+                                                            uint8_t* __restrict__ blob, unsigned long long blob_bytes,
+                                                            int32_t* __restrict__ status) {
+    constexpr int CHUNK = 256;
+    __shared__ int cx[CHUNK], cy[CHUNK];
+    __shared__ long long r2[CHUNK];
+    __shared__ int bad;
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_disc_job job = jobs[j];
+    const bool lead = blockIdx.y == 0 && threadIdx.x == 0;
+    const unsigned long long npix = (unsigned long long)(unsigned)max(job.w, 0) * (unsigned)max(job.h, 0);
+    const bool ok = job.w >= 1 && job.h >= 1 && job.w <= (1 << 14) && job.h <= (1 << 14) && job.mask_off >= 0 &&
+                    (unsigned long long)job.mask_off + npix <= blob_bytes && job.circle_begin >= 0 && job.circle_count >= 0 &&
+                    (long long)job.circle_begin + job.circle_count <= (long long)ncircles;
+    if (!ok) { if (lead && status) status[j] = SLAM_HIP_EINVAL; return; }
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int c = threadIdx.x; c < job.circle_count; c += WARP_WG)
+        if (circles[3 * (job.circle_begin + c) + 2] < 0) bad = 1;          // cv::circle asserts radius >= 0
+    __syncthreads();
+    if (bad) { if (lead && status) status[j] = SLAM_HIP_EINVAL; return; }
+    if (lead && status) status[j] = SLAM_HIP_OK;
+    uint8_t* M = blob + job.mask_off;
+    const int total = (int)npix;
+    const int span = gridDim.y * WARP_WG;
+    const int iters = (total + span - 1) / span;                            // the same for every lane: barriers inside
+    for (int it = 0; it < iters; it++) {
+        const int i = it * span + blockIdx.y * WARP_WG + threadIdx.x;
+        const int y = i / job.w, x = i - y * job.w;
+        bool in = false;
+        for (int c0 = 0; c0 < job.circle_count; c0 += CHUNK) {
+            const int nc = min(CHUNK, job.circle_count - c0);
+            __syncthreads();
+            if ((int)threadIdx.x < nc) {
+                const int32_t* c = circles + 3 * (size_t)(job.circle_begin + c0 + threadIdx.x);
+                cx[threadIdx.x] = c[0]; cy[threadIdx.x] = c[1]; r2[threadIdx.x] = (long long)c[2] * c[2];
+            }
+            __syncthreads();
+            for (int c = 0; c < nc && !in; c++) {
+                const long long ddx = (long long)x - cx[c], ddy = (long long)y - cy[c];
+                in = ddx * ddx + ddy * ddy <= r2[c];
+            }
+        }
+        if (i < total) M[i] = in ? 255 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int slam_hip_disc_masks_d(slam_ctx* ctx, const int32_t* d_circles, int ncircles, const slam_disc_job* d_jobs,
+                                     int njobs, uint8_t* d_blob, size_t blob_bytes, int32_t* d_status, int max_pixels) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || ncircles < 0 || (njobs > 0 && (!d_jobs || !d_blob)) || (ncircles > 0 && !d_circles))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "disc_masks: null table or negative count");
+    if (njobs == 0) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int slices = max_pixels > 0 ? (max_pixels + WARP_WG * 16 - 1) / (WARP_WG * 16) : 1;
+    slices = std::min(std::max(slices, 1), 64);
+    hipLaunchKernelGGL(disc_mask_kernel, dim3(njobs, slices), dim3(WARP_WG), 0, ctx->stream, d_circles, ncircles, d_jobs,
+                       njobs, d_blob, (unsigned long long)blob_bytes, d_status);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    return SLAM_HIP_OK;
+}
+
+// SLAM::matchLines' image work for one frame batch, host tables (matching.cpp:279-292 around
+// lineFeature.cpp:86-165): the area masks are rasterised on the device from the projected cone bins and
+// searched there; only the descriptors, the circle table and the results cross the bus.
+extern "C" int slam_hip_match_lines_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* jobs, int njobs,
+                                          const int32_t* circles, int ncircles, const int32_t* circle_begin,
+                                          const uint8_t* desc_blob, size_t desc_bytes, slam_track_result* out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || ncircles < 0 || (njobs > 0 && (!jobs || !circle_begin || !desc_blob || !out)) || (ncircles > 0 && !circles))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_lines_batch: null table or negative count");
+    if (!pyr) return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_lines_batch: no pyramid");
+    if (njobs == 0) return SLAM_HIP_OK;
+    std::vector<slam_line_job> lj(jobs, jobs + njobs);
+    std::vector<slam_disc_job> dj((size_t)njobs);
+    size_t off = (desc_bytes + 255) / 256 * 256;
+    int max_pix = 0;
+    for (int i = 0; i < njobs; i++) {
+        if (circle_begin[i] < 0 || circle_begin[i + 1] < circle_begin[i] || circle_begin[i + 1] > ncircles)
+            return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_lines_batch: job %d: circle range", i);
+        const bool live = lj[i].aw >= 1 && lj[i].ah >= 1 && lj[i].aw <= (1 << 12) && lj[i].ah <= (1 << 12);
+        const size_t n = live ? (size_t)lj[i].aw * lj[i].ah : 0;
+        dj[i].mask_off = (int64_t)off; dj[i].w = lj[i].aw; dj[i].h = lj[i].ah;
+        dj[i].circle_begin = circle_begin[i]; dj[i].circle_count = circle_begin[i + 1] - circle_begin[i];
+        lj[i].amask_off = (int64_t)off;
+        off += n;
+        max_pix = std::max(max_pix, (int)n);
+    }
+    for (int c = 0; c < ncircles; c++)
+        if (circles[3 * c + 2] < 0) return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_lines_batch: circle %d has a negative radius", c);
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t lb = sizeof(slam_line_job) * (size_t)njobs, db = sizeof(slam_disc_job) * (size_t)njobs;
+    const size_t rb = sizeof(slam_track_result) * (size_t)njobs, cb = 12 * (size_t)ncircles;
+    const size_t o_d = (lb + 255) / 256 * 256, o_r = o_d + (db + 255) / 256 * 256, o_c = o_r + (rb + 255) / 256 * 256;
+    int rc;
+    if ((rc = slam_stage_reserve(ctx, 0, o_c + cb + 16)) || (rc = slam_stage_reserve(ctx, 1, off + 16))) return rc;
+    uint8_t* t0 = (uint8_t*)ctx->d_stage[0];
+    uint8_t* blob = (uint8_t*)ctx->d_stage[1];
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(t0, lj.data(), lb, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(t0 + o_d, dj.data(), db, hipMemcpyHostToDevice, ctx->stream));
+    if (cb) SLAM_HIP_CHECK(ctx, hipMemcpyAsync(t0 + o_c, circles, cb, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(blob, desc_blob, desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = slam_hip_disc_masks_d(ctx, (const int32_t*)(t0 + o_c), ncircles, (const slam_disc_job*)(t0 + o_d), njobs, blob, off,
+                               nullptr, max_pix);
+    if (rc != SLAM_HIP_OK) return rc;
+    rc = slam_hip_line_track_batch_d(ctx, pyr, (const slam_line_job*)t0, njobs, blob, off ? off : 1, (slam_track_result*)(t0 + o_r));
+    if (rc != SLAM_HIP_OK) return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, t0 + o_r, rb, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}

@@ -251,6 +251,71 @@ void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Proj
     }
 }
 
+void SLAM::matchLines(const ImagePyramid<byte>& pyramid, const std::vector<LineSearch>& lines, std::vector<Match>& matches,
+                      float threshold, int stride, std::vector<float>* responses) {
+    matches.clear();
+    if (responses) responses->assign(lines.size(), -1.f);
+    if (lines.empty()) return;
+    std::vector<slam_line_job> jobs(lines.size());
+    std::vector<int32_t> circles, begin(lines.size() + 1, 0);
+    std::vector<uint8_t> blob;
+    for (size_t i = 0; i < lines.size(); i++) {
+        const LineSearch& l = lines[i];
+        if (l.binCenters.size() != l.binRadii.size()) throw std::invalid_argument("matchLines: one radius per bin centre");
+        slam_line_job& j = jobs[i];
+        std::memset(&j, 0, sizeof(j));
+        j.desc_off = (int64_t)blob.size();
+        for (int r = 0; r < l.descriptor.rows; r++) blob.insert(blob.end(), l.descriptor.ptr(r), l.descriptor.ptr(r) + l.descriptor.cols);
+        j.amask_off = -1;
+        j.dw = l.descriptor.cols; j.dh = l.descriptor.rows;
+        j.ax = l.areaRect.x; j.ay = l.areaRect.y; j.aw = l.areaRect.width; j.ah = l.areaRect.height;
+        j.threshold = threshold; j.stride = stride;
+        for (size_t k = 0; k < l.binCenters.size(); k++) {
+            circles.push_back(l.binCenters[k].x); circles.push_back(l.binCenters[k].y); circles.push_back(l.binRadii[k]);
+        }
+        begin[i + 1] = (int32_t)(circles.size() / 3);
+    }
+    if (blob.empty()) blob.push_back(0);
+    std::vector<slam_track_result> res(lines.size());
+    slamhip::check(slam_hip_match_lines_batch(slamhip::context(), pyramid.device(), jobs.data(), (int)jobs.size(),
+                                              circles.empty() ? nullptr : circles.data(), (int)(circles.size() / 3), begin.data(),
+                                              blob.data(), blob.size(), res.data()),
+                   "matchLines");
+    for (size_t i = 0; i < res.size(); i++) {
+        if (res[i].status != SLAM_HIP_OK) throw std::invalid_argument("matchLines: job rejected by the device");
+        if (responses) (*responses)[i] = res[i].response;
+        if (res[i].response > threshold)      // matching.cpp:288
+            matches.push_back(Match(cv::Point2f((float)res[i].x, (float)res[i].y), (int)i));
+    }
+}
+
+matb SLAM::lineAreaMask(const LineSearch& l) {
+    if (l.areaRect.width <= 0 || l.areaRect.height <= 0) return matb();
+    slam_ctx* ctx = slamhip::context();
+    const size_t npix = (size_t)l.areaRect.width * l.areaRect.height, nc = l.binCenters.size();
+    std::vector<int32_t> circles;
+    for (size_t k = 0; k < nc; k++) { circles.push_back(l.binCenters[k].x); circles.push_back(l.binCenters[k].y); circles.push_back(l.binRadii[k]); }
+    slam_disc_job job;
+    job.mask_off = 0; job.w = l.areaRect.width; job.h = l.areaRect.height; job.circle_begin = 0; job.circle_count = (int32_t)nc;
+    void *d_c = nullptr, *d_j = nullptr, *d_m = nullptr;
+    matb out(l.areaRect.height, l.areaRect.width);
+    int32_t st = SLAM_HIP_OK;
+    int rc = slam_hip_malloc(ctx, 12 * nc + 16, &d_c);
+    if (rc == SLAM_HIP_OK) rc = slam_hip_malloc(ctx, sizeof(job) + 16, &d_j);
+    if (rc == SLAM_HIP_OK) rc = slam_hip_malloc(ctx, npix, &d_m);
+    if (rc == SLAM_HIP_OK && nc) rc = slam_hip_memcpy_h2d(ctx, d_c, circles.data(), 12 * nc);
+    if (rc == SLAM_HIP_OK) rc = slam_hip_memcpy_h2d(ctx, d_j, &job, sizeof(job));
+    if (rc == SLAM_HIP_OK)
+        rc = slam_hip_disc_masks_d(ctx, (const int32_t*)d_c, (int)nc, (const slam_disc_job*)d_j, 1, (uint8_t*)d_m, npix,
+                                   (int32_t*)((uint8_t*)d_j + sizeof(job)), (int)npix);
+    if (rc == SLAM_HIP_OK) rc = slam_hip_memcpy_d2h(ctx, &st, (uint8_t*)d_j + sizeof(job), 4);
+    if (rc == SLAM_HIP_OK && st == SLAM_HIP_OK) rc = slam_hip_memcpy_d2h(ctx, out.data, d_m, npix);
+    slam_hip_free(ctx, d_c); slam_hip_free(ctx, d_j); slam_hip_free(ctx, d_m);
+    slamhip::check(rc, "lineAreaMask");
+    if (st != SLAM_HIP_OK) throw std::invalid_argument("lineAreaMask: negative radius");
+    return out;
+}
+
 std::vector<int> SLAM::selectNewPoints(const matb& im, const std::vector<cv::KeyPoint>& keypoints,
                                        const std::vector<Match>& matches, const std::vector<Match>& lineMatches,
                                        int n, float minDist, int rx, int ry, std::vector<matb>* descriptors) {

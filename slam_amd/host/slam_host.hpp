@@ -5,6 +5,7 @@
 //   ImagePyramid<byte>             imagePyramid.hpp:9-34
 //   SLAM::Feature::project         SLAM.hpp:57-58, feature.cpp:53-100
 //   SLAM::Feature::track           SLAM.hpp:62-65, feature.cpp:102-173
+//   SLAM::matchLines               SLAM.hpp:108-109, matching.cpp:271-310 (the image work of LineFeature::track)
 //   SLAM::getSortedKeyPoints       SLAM.hpp:118-119, new_point.cpp:113-127
 //   SLAM::matchPoints              SLAM.hpp:106-107, matching.cpp:230-269 (batched over features)
 // Device errors (no GPU, failed allocation) are reported by std::runtime_error; the reference's own
@@ -112,6 +113,24 @@ public:
                             const std::vector<Feature>& features, const std::vector<matf>& p3ds,
                             std::vector<Match>& matches, float threshold = .95f, int stride = 3,
                             std::vector<float>* responses = nullptr);
+
+    // What LineFeature::track (lineFeature.cpp:22-96) has computed on the CPU from the cone before it
+    // touches the image: the descriptor, the area rectangle on the coarsest level and the projected
+    // relevant bins as circles relative to that rectangle (lineFeature.cpp:86-96).
+    struct LineSearch {
+        matb descriptor;
+        cv::Rect areaRect;
+        std::vector<cv::Point2i> binCenters;
+        std::vector<int> binRadii;
+    };
+    // lineFeature.cpp:87-96: the area mask (0 / 255) of one LineSearch, drawn on the device.
+    static matb lineAreaMask(const LineSearch& line);
+    // The image work of SLAM::matchLines (matching.cpp:279-292) for all lines of a frame in one device
+    // pass: masks drawn, coarsest level searched inside them, finer levels refined (lineFeature.cpp:120-165).
+    // Keeps Match(pos, i) when response > threshold; pyramid {1,2} and stride 2 are matching.cpp:273-277.
+    static void matchLines(const ImagePyramid<byte>& pyramid, const std::vector<LineSearch>& lines,
+                           std::vector<Match>& matches, float threshold = .95f, int stride = 2,
+                           std::vector<float>* responses = nullptr);
 
     // The selection loop of SLAM::addNewLines (new_point.cpp:137-155) and the descriptor crop of the
     // kept points (lineFeature.cpp:7-10): `keypoints` as returned by getSortedKeyPoints; a point is

@@ -250,6 +250,67 @@ static bool test_project_track() {
     return true;
 }
 
+// SLAM::matchLines' image work (lineFeature.cpp:86-165) against the oracle: pyramid {1,2}, stride 2 (matching.cpp:273-277).
+static bool test_match_lines() {
+    const int w = 640, h = 480;
+    matb im0(h, w), im(h, w);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            im0(y, x) = (byte)(((x / 11) * 53 + (y / 6) * 29 + ((x * 5 + y * 3) % 19)) & 0xFF);
+            const int xs = x - 3, ys = y + 2;
+            im(y, x) = (byte)(((xs / 11) * 53 + (ys / 6) * 29 + ((xs * 5 + ys * 3) % 19)) & 0xFF);
+        }
+    std::vector<float> subs;
+    subs.push_back(1.f); subs.push_back(2.f);
+    ImagePyramid<byte> pyramid(im, subs);
+    uint8_t* lev[2]; int lw[2], lh[2];
+    std::vector<std::vector<uint8_t> > store(2);
+    for (int i = 0; i < 2; i++) {
+        so_pyramid_level_size(w, h, subs[i], &lw[i], &lh[i]);
+        store[i].resize((size_t)lw[i] * lh[i]);
+        lev[i] = store[i].data();
+    }
+    so_pyramid_build(im.data, w, h, (ptrdiff_t)im.step, 2, subs.data(), lev);
+    std::vector<SLAM::LineSearch> lines;
+    for (int k = 0; k < 10; k++) {
+        const int cx = 80 + 50 * k, cy = 90 + 30 * k, half = 20;          // the descriptor of new_image.cpp:80-82 is 81x81; 41x41 here
+        SLAM::LineSearch l;
+        l.descriptor = im0(Rect(cx - half, cy - half, 2 * half + 1, 2 * half + 1)).clone();
+        const int tx = (cx + 3) / 2, ty = (cy - 2) / 2;                    // true position on the coarsest level
+        l.areaRect = Rect(tx - 14, ty - 9, 30, 20);
+        for (int b = 0; b < 5; b++) { l.binCenters.push_back(Point2i(4 + 5 * b + (k % 3), 5 + 2 * b)); l.binRadii.push_back(2 + (b + k) % 4); }
+        lines.push_back(l);
+    }
+    lines[9].areaRect = Rect(-8, -6, 30, 20);                              // hangs over the image corner
+    std::vector<SLAM::Match> matches;
+    std::vector<float> resp;
+    SLAM::matchLines(pyramid, lines, matches, 0.9f, 2, &resp);
+    size_t nm = 0, both = 0;
+    for (size_t k = 0; k < lines.size(); k++) {
+        const SLAM::LineSearch& l = lines[k];
+        std::vector<int> circ;
+        for (size_t b = 0; b < l.binCenters.size(); b++) { circ.push_back(l.binCenters[b].x); circ.push_back(l.binCenters[b].y); circ.push_back(l.binRadii[b]); }
+        std::vector<uint8_t> mask((size_t)l.areaRect.width * l.areaRect.height);
+        so_disc_mask(l.areaRect.width, l.areaRect.height, circ.data(), (int)l.binRadii.size(), mask.data());
+        const matb gm = SLAM::lineAreaMask(l);
+        for (int y = 0; y < gm.rows; y++)
+            if (std::memcmp(gm.ptr(y), mask.data() + (size_t)y * gm.cols, gm.cols) != 0) { printf("line %zu: mask row %d differs\n", k, y); return false; }
+        so_track_out o;
+        so_line_track(lev, lw, lh, subs.data(), 2, l.descriptor.data, l.descriptor.cols, l.descriptor.rows, l.areaRect.x, l.areaRect.y,
+                      l.areaRect.width, l.areaRect.height, mask.data(), 0.9f, 2, &o);
+        const bool kept = nm < matches.size() && matches[nm].iFeature == (int)k;
+        if (std::memcmp(&resp[k], &o.response, 4) != 0 || kept != (o.response > 0.9f) ||
+            (kept && (matches[nm].pos.x != (float)o.x || matches[nm].pos.y != (float)o.y))) {
+            printf("line %zu: HIP response %.9g kept %d, oracle (%d,%d,%.9g)\n", k, resp[k], (int)kept, o.x, o.y, o.response);
+            return false;
+        }
+        nm += kept;
+        both += o.levels_run == 2;
+    }
+    if (nm != matches.size() || both < 5) { printf("lines: %zu matches, %zu refined\n", nm, both); return false; }
+    return true;
+}
+
 int main(int argc, char* argv[]) {
     const int nTrials = argc > 1 ? std::atoi(argv[1]) : 100;
     int failed = 0;
@@ -262,6 +323,7 @@ int main(int argc, char* argv[]) {
         DO_TEST("test_matchingPatchArea", test_matching0(true, true, nTrials));
         DO_TEST("test_pyramid_track_keypoints", test_pyramid_track_keypoints());
         DO_TEST("test_project_track", test_project_track());
+        DO_TEST("test_match_lines", test_match_lines());
     } catch (const std::exception& e) {
         printf("exception: %s\n", e.what());
         return 2;

@@ -1,0 +1,114 @@
+"""GPU parity of the image work of SLAM::LineFeature::track (lineFeature.cpp:86-165): the disc area mask against
+the oracle's restatement of cv::circle, and the searches (coarsest level inside the area mask, finer levels in
+small windows) against the oracle's walk.  Parity unpinned: no test of the reference covers LineFeature."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from slam_amd import api, capi, synth
+
+DevBuf = api.DeviceBuffer
+
+pytestmark = pytest.mark.gpu
+
+
+def _disc_masks(ctx, jobs, hint=0):
+    """jobs: list of (w, h, circles[k,3]).  One slam_hip_disc_masks_d call; returns [(mask, status)]."""
+    n = len(jobs)
+    arr = (capi.DiscJob * n)()
+    circ, off = [], 0
+    for i, (w, h, cs) in enumerate(jobs):
+        cs = np.asarray(cs, np.int32).reshape(-1, 3)
+        arr[i].mask_off, arr[i].w, arr[i].h = off, w, h
+        arr[i].circle_begin, arr[i].circle_count = sum(len(c) for c in circ), len(cs)
+        circ.append(cs)
+        off += max(w, 0) * max(h, 0)
+    allc = np.concatenate(circ) if circ else np.zeros((0, 3), np.int32)
+    d_c = DevBuf(ctx, allc if len(allc) else np.zeros(3, np.int32))
+    d_j = DevBuf(ctx, np.frombuffer(bytes(arr), np.uint8).copy())
+    d_b = DevBuf(ctx, nbytes=off + 64, fill=0x5A)
+    d_s = DevBuf(ctx, nbytes=4 * n, fill=0x7F)
+    capi.check(ctx.handle, capi.lib().slam_hip_disc_masks_d(ctx.handle, d_c.ptr, len(allc), d_j.ptr, n, d_b.ptr, off, d_s.ptr, hint))
+    ctx.synchronize()
+    blob, st = d_b.get(), d_s.get(np.int32)
+    for b in (d_c, d_j, d_b, d_s):
+        b.free()
+    assert (blob[off:] == 0x5A).all()
+    return [(blob[arr[i].mask_off:arr[i].mask_off + max(w, 0) * max(h, 0)].reshape(max(h, 0), max(w, 0)), int(st[i]))
+            for i, (w, h, _) in enumerate(jobs)]
+
+
+def test_disc_masks_match_cv_circle(ctx, oracle):
+    rng = np.random.default_rng(3)
+    jobs = []
+    for i in range(60):
+        w, h = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        k = int(rng.integers(0, 60))
+        cs = np.stack([rng.integers(-40, w + 40, k), rng.integers(-40, h + 40, k), rng.integers(0, 45, k)], 1)
+        jobs.append((w, h, cs))
+    jobs.append((300, 300, [[150, 150, 149], [0, 0, 0], [299, 299, 1], [-500, 10, 505]]))
+    jobs.append((64, 48, np.stack([rng.integers(0, 64, 700), rng.integers(0, 48, 700), rng.integers(0, 3, 700)], 1)))   # > one LDS chunk
+    jobs.append((17, 9, np.zeros((0, 3), np.int32)))                                                                  # no relevant bin
+    for hint in (0, 90000):
+        got = _disc_masks(ctx, jobs, hint)
+        for (w, h, cs), (m, st) in zip(jobs, got):
+            assert st == 0
+            assert np.array_equal(m, oracle.disc_mask(w, h, cs)), (w, h, len(cs))
+    bad = _disc_masks(ctx, [(8, 8, [[4, 4, -1]]), (8, 8, [[4, 4, 2]])])
+    assert bad[0][1] == capi.EINVAL and (bad[0][0] == 0x5A).all()
+    assert bad[1][1] == 0 and bad[1][0].sum() == 13 * 255
+
+
+def _line_jobs(rng, w, h, subs, n, half, frame0, shift):
+    """Line features cut from frame0; the search area on the coarsest level is a chain of discs (projected cone bins)
+    around the true position in the shifted frame."""
+    top = float(subs[-1])
+    jobs = []
+    for (cx, cy) in synth.feature_grid(w, h, n, half + 40, rng):
+        d = synth.cut_template(frame0, cx, cy, 2 * half + 1, 2 * half + 1)
+        tx, ty = (cx - shift[0]) / top, (cy - shift[1]) / top
+        k = int(rng.integers(3, 9))
+        ang = rng.uniform(0, np.pi)
+        ts = np.linspace(-1, 1, k) * rng.uniform(4, 30) / top
+        cs = np.stack([tx + ts * np.cos(ang) + rng.uniform(-1, 1), ty + ts * np.sin(ang) + rng.uniform(-1, 1),
+                       rng.integers(2, 9, k)], 1)
+        x0, y0 = int(np.floor((cs[:, 0] - cs[:, 2]).min())), int(np.floor((cs[:, 1] - cs[:, 2]).min()))
+        x1, y1 = int(np.ceil((cs[:, 0] + cs[:, 2] + 1).max())), int(np.ceil((cs[:, 1] + cs[:, 2] + 1).max()))
+        circ = np.stack([np.round(cs[:, 0]) - x0, np.round(cs[:, 1]) - y0, cs[:, 2]], 1).astype(np.int32)
+        jobs.append(dict(frame=0, descriptor=d, area=(x0, y0, x1 - x0, y1 - y0), circles=circ, threshold=0.9, stride=2))
+    return jobs
+
+
+@pytest.mark.parametrize("subs,half,n", [([1.0, 2.0], 20, 24), ([1.0, 2.0, 4.0], 12, 16), ([1.0], 7, 8), ([1.0, 3.0], 40, 6)])
+def test_line_track_matches_oracle(ctx, oracle, subs, half, n):
+    rng = np.random.default_rng(60 + half)
+    w, h = 640, 480
+    shift = (4, -3)
+    f0, f1 = synth.frame(w, h, 23), synth.frame(w, h, 23, shift)
+    jobs = _line_jobs(rng, w, h, subs, n, half, f0, shift)
+    for j in jobs:
+        j["area_mask"] = oracle.disc_mask(j["area"][2], j["area"][3], j["circles"])
+    # one area hanging over the image corner, one entirely outside (matching.cpp:26-30), one below the threshold
+    jobs.append(dict(jobs[0], area=(-5, -7, 30, 25), area_mask=oracle.disc_mask(30, 25, [[12, 12, 11]])))
+    jobs.append(dict(jobs[0], area=(5000, 10, 9, 9), area_mask=np.full((9, 9), 255, np.uint8)))
+    jobs.append(dict(jobs[1], descriptor=255 - jobs[1]["descriptor"][::-1].copy(), threshold=0.999))
+    pyr = api.ImagePyramid(ctx, f1, subs)
+    try:
+        got = api.line_track_batch(ctx, pyr, jobs)
+        fused = api.match_lines_batch(ctx, pyr, jobs[:n])          # masks drawn on the device from the circles
+    finally:
+        pyr.close()
+    assert fused == got[:n]
+    levels = oracle.pyramid(f1, subs)
+    full = 0
+    for j, g in zip(jobs, got):
+        r = oracle.line_track(levels, subs, j["descriptor"], j["area"], j["area_mask"], j["threshold"], j["stride"])
+        assert g["status"] == 0
+        assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"]), (j["area"], g, r)
+        assert np.float32(g["response"]).view(np.uint32) == np.float32(r["response"]).view(np.uint32)
+        assert np.float32(g["dx"]).view(np.uint32) == np.float32(r["dx"]).view(np.uint32)
+        assert np.float32(g["dy"]).view(np.uint32) == np.float32(r["dy"]).view(np.uint32)
+        full += r["levels_run"] == len(subs)
+    assert full >= n // 2
+    assert got[-2]["response"] == -1.0 and (got[-2]["x"], got[-2]["y"]) == (0, 0)

@@ -10,29 +10,7 @@ from slam_amd import api, capi, synth
 pytestmark = pytest.mark.gpu
 
 
-class DevBuf:
-    """Device buffer through the ABI's own memory helpers (no second HIP runtime in the process)."""
-
-    def __init__(self, ctx, host=None, nbytes=None):
-        self.ctx, self.L = ctx, capi.lib()
-        self.nbytes = int(host.nbytes if host is not None else nbytes)
-        p = C.c_void_p()
-        capi.check(ctx.handle, self.L.slam_hip_malloc(ctx.handle, max(self.nbytes, 16), C.byref(p)))
-        self.ptr = p
-        if host is not None:
-            h = np.ascontiguousarray(host)
-            capi.check(ctx.handle, self.L.slam_hip_memcpy_h2d(ctx.handle, self.ptr, h.ctypes.data, self.nbytes))
-        else:
-            z = np.zeros(max(self.nbytes, 1), np.uint8)
-            capi.check(ctx.handle, self.L.slam_hip_memcpy_h2d(ctx.handle, self.ptr, z.ctypes.data, self.nbytes))
-
-    def get(self, dtype):
-        out = np.zeros(self.nbytes, np.uint8)
-        capi.check(self.ctx.handle, self.L.slam_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
-        return out.view(dtype)
-
-    def free(self):
-        self.L.slam_hip_free(self.ctx.handle, self.ptr)
+DevBuf = api.DeviceBuffer
 
 
 def _ref_path(oracle, frame, kps_fast_order, occ, n_new, min_dist, rx, ry):

@@ -12,27 +12,7 @@ from slam_amd import api, capi, synth
 pytestmark = pytest.mark.gpu
 
 
-class DevBuf:
-    """Device buffer through the ABI's own memory helpers."""
-
-    def __init__(self, ctx, host=None, nbytes=None, fill=0):
-        self.ctx, self.L = ctx, capi.lib()
-        if host is None:
-            host = np.full(max(int(nbytes), 1), fill, np.uint8)
-        h = np.ascontiguousarray(host)
-        self.nbytes = int(h.nbytes)
-        p = C.c_void_p()
-        capi.check(ctx.handle, self.L.slam_hip_malloc(ctx.handle, max(self.nbytes, 16), C.byref(p)))
-        self.ptr = p
-        capi.check(ctx.handle, self.L.slam_hip_memcpy_h2d(ctx.handle, self.ptr, h.ctypes.data, self.nbytes))
-
-    def get(self, dtype=np.uint8):
-        out = np.zeros(self.nbytes, np.uint8)
-        capi.check(self.ctx.handle, self.L.slam_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
-        return out.view(dtype)
-
-    def free(self):
-        self.L.slam_hip_free(self.ctx.handle, self.ptr)
+DevBuf = api.DeviceBuffer
 
 
 def _warp_batch(ctx, cases, want_mask=True, hint=0):

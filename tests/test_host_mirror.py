@@ -19,7 +19,7 @@ def _built():
 def test_host_library_exports_reference_names():
     _built()
     out = subprocess.check_output(["nm", "-DC", "--defined-only", os.path.join(LIB, "libslam_host.so")], text=True)
-    for name in ["SLAM::matchFeatureInArea(", "ImagePyramid<unsigned char>::ImagePyramid(", "SLAM::Feature::track(", "SLAM::Feature::project(", "SLAM::CameraState::project(",
+    for name in ["SLAM::matchFeatureInArea(", "ImagePyramid<unsigned char>::ImagePyramid(", "SLAM::Feature::track(", "SLAM::Feature::project(", "SLAM::CameraState::project(", "SLAM::matchLines(",
                  "SLAM::matchPoints(", "SLAM::getSortedKeyPoints(", "slamhip::context()"]:
         assert name in out, name
     # the product library is reached only through the C ABI: no oracle symbols, no oracle dependency
@@ -34,4 +34,4 @@ def test_reference_matching_tests_through_cpp_interface():
     r = subprocess.run([exe, os.environ.get("SLAM_PROP_TRIALS", "100")], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, "exit status %d\n" % r.returncode + r.stdout + r.stderr
-    assert r.stdout.count("passed") == 6
+    assert r.stdout.count("passed") == 7
