@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Times the two HBM-bound kernels of the path on their own, with inputs resident in HBM:
+"""Times the kernels around the search on their own, with inputs resident in HBM:
   - the pyramid build (C2: 1024 frames 640x480 {1,2,4}; C3: 256 frames 1280x720 {1,2,4,8})
-  - FAST-9-16 + NMS (C4: 64 frames 1920x1080)
+  - FAST-9-16 + NMS (C4: 64 frames 1920x1080), then the keypoint sort and the new-point selection on its output
+  - the template projection (warp) of 65536 21x21 descriptors, alone and chained with the search
+  - the line-feature path: disc area masks and the 81x81-descriptor searches of 3 lines per frame, 1024 frames
 and prints the achieved fraction of the 8 TB/s HBM peak on the algorithmic bytes.
 Diagnostic tool (the contract benchmark is bench.py)."""
 import ctypes as C
@@ -68,6 +70,115 @@ def main():
         gbs = alg / (ms * 1e-3) / 1e9
         out["fast_c4_thr%d" % thr] = {"ms": ms, "frames": nfr, "mean_corners_per_frame": float(cnt.mean()), "GB/s": gbs,
                                      "frac_hbm": gbs / 8000.0, "Gpx/s": w * h * nfr / (ms * 1e-3) / 1e9}
+
+    # --- keypoint sort + addNewLines selection on the FAST output above (thr 40), new_image.cpp:80-82 parameters
+    d_sorted = torch.zeros(nfr * cap * 12, dtype=torch.uint8, device=dev)
+    n_new = 3
+    d_sel = torch.zeros(nfr * n_new, dtype=torch.int32, device=dev)
+    d_nsel = torch.zeros(nfr, dtype=torch.int32, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    ms = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_sort_keypoints_d(ctx.handle, P(d_out), P(d_cnt), nfr, cap, P(d_sorted))))
+    nk = int(np.minimum(d_cnt.cpu().numpy(), cap).sum())
+    out["sort_keypoints_c4_thr40"] = {"ms": ms, "keypoints": nk, "GB/s": 24.0 * nk / (ms * 1e-3) / 1e9, "frac_hbm": 24.0 * nk / (ms * 1e-3) / 8e12}
+    ms = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_select_new_points_d(
+        ctx.handle, P(d_sorted), P(d_cnt), nfr, cap, None, None, n_new, 100.0, 40, 40, w, h, P(d_sel), P(d_nsel))))
+    out["select_new_points_c4"] = {"ms": ms, "frames": nfr, "kept_per_frame": float(d_nsel.float().mean().item())}
+    del d, d_scr, d_out, d_cnt, d_sorted
+
+    # --- template projection: 1024 frames x 64 features, 21x21 descriptors, mild homographies
+    w, h, nfr, nfeat, ds = 640, 480, 1024, 64, 21
+    rng = np.random.default_rng(7)
+    f0 = synth.frame(w, h, 5)
+    f1 = synth.frame(w, h, 5, (3, -2))
+    Pm = synth.camera(w, h, rng)
+    pts = synth.feature_grid(w, h, nfeat, 60, rng)
+    wj = (capi.WarpJob * (nfr * nfeat))()
+    tj = (capi.TrackJob * (nfr * nfeat))()
+    descs, off_in, off_out, alg_warp = [], 0, 0, 0
+    for k, (cx, cy) in enumerate(pts):
+        B, p3d, p2d = synth.plane_feature(Pm, cx, cy, rng)
+        s = api.project_setup(Pm, B, p3d, ds, ds)
+        assert s["valid"]
+        descs.append(synth.cut_template(f0, cx, cy, ds, ds).reshape(-1))
+        for f in range(nfr):
+            j, t = wj[f * nfeat + k], tj[f * nfeat + k]
+            j.desc_off, j.dw, j.dh, j.ow, j.oh = k * ds * ds, ds, ds, s["loc"][2], s["loc"][3]
+            for q in range(9):
+                j.m[q] = float(s["m"].reshape(9)[q])
+            t.frame, t.projw, t.projh = f, j.ow, j.oh
+            t.px, t.py, t.threshold, t.stride = float(p2d[0]) - 3, float(p2d[1]) + 2, 0.98, 3
+    for i in range(nfr * nfeat):
+        n = wj[i].ow * wj[i].oh
+        wj[i].proj_off = tj[i].proj_off = off_out
+        wj[i].mask_off = tj[i].mask_off = off_out + n
+        off_out += 2 * n
+        alg_warp += ds * ds + 2 * n + 80
+    d_desc = torch.from_numpy(np.concatenate(descs)).to(dev)
+    d_wj = torch.from_numpy(np.frombuffer(bytes(wj), np.uint8).copy()).to(dev)
+    d_tj = torch.from_numpy(np.frombuffer(bytes(tj), np.uint8).copy()).to(dev)
+    d_blob = torch.zeros(off_out + 64, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(nfr * nfeat * 28, dtype=torch.uint8, device=dev)
+    d_fr = torch.from_numpy(f1).to(dev).unsqueeze(0).repeat(nfr, 1, 1).contiguous()
+    pyr = api.ImagePyramid(ctx, None, [1.0, 2.0, 4.0], device_ptr=d_fr.data_ptr(), pitch=w, frame_stride=w * h, shape=(nfr, h, w))
+
+    def warp():
+        capi.check(ctx.handle, L.slam_hip_warp_batch_d(ctx.handle, P(d_desc), d_desc.numel(), P(d_wj), nfr * nfeat, P(d_blob), off_out, None, 441))
+
+    def track():
+        capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_tj), nfr * nfeat, P(d_blob), off_out, P(d_res)))
+    ms = timed(stream, warp)
+    out["warp_c2_65536x21x21"] = {"ms": ms, "jobs": nfr * nfeat, "alg_bytes": alg_warp, "GB/s": alg_warp / (ms * 1e-3) / 1e9,
+                                 "frac_hbm": alg_warp / (ms * 1e-3) / 8e12, "Gpx/s": off_out / 2 / (ms * 1e-3) / 1e9}
+    ms_t = timed(stream, track)
+    ms_wt = timed(stream, lambda: (warp(), track()))
+    res = d_res.cpu().numpy().view(np.int32).reshape(-1, 7)
+    out["project_then_track_c2"] = {"ms_track_alone": ms_t, "ms_warp_plus_track": ms_wt,
+                                    "tracked_all_levels": float((res[:, 5] == 3).mean())}
+    pyr.close()
+    del d_desc, d_wj, d_tj, d_blob, d_res
+
+    # --- line features: 3 lines per frame (new_image.cpp:80: 3 - nLines), 81x81 descriptors, pyramid {1,2}, stride 2
+    nline, half = 3, 40
+    pyr = api.ImagePyramid(ctx, None, [1.0, 2.0], device_ptr=d_fr.data_ptr(), pitch=w, frame_stride=w * h, shape=(nfr, h, w))
+    lj = (capi.LineJob * (nfr * nline))()
+    dj = (capi.DiscJob * (nfr * nline))()
+    descs, circ, off = [], [], 0
+    centres = [(160, 140), (330, 250), (500, 330)]
+    for k, (cx, cy) in enumerate(centres):
+        descs.append(synth.cut_template(f0, cx, cy, 2 * half + 1, 2 * half + 1).reshape(-1))
+    off = sum(d.size for d in descs)
+    alg_disc = 0
+    for f in range(nfr):
+        for k, (cx, cy) in enumerate(centres):
+            i = f * nline + k
+            tx, ty = (cx - 3) // 2, (cy + 2) // 2
+            aw, ah = 60, 40
+            cs = [[6 + 6 * b, 8 + 3 * b, 4 + (b + k) % 4] for b in range(8)]
+            lj[i].desc_off, lj[i].dw, lj[i].dh = k * (2 * half + 1) ** 2, 2 * half + 1, 2 * half + 1
+            lj[i].frame, lj[i].ax, lj[i].ay, lj[i].aw, lj[i].ah = f, tx - 27, ty - 17, aw, ah
+            lj[i].amask_off, lj[i].threshold, lj[i].stride = off, 0.9, 2
+            dj[i].mask_off, dj[i].w, dj[i].h, dj[i].circle_begin, dj[i].circle_count = off, aw, ah, len(circ), len(cs)
+            circ += cs
+            off += aw * ah
+            alg_disc += aw * ah + 12 * len(cs) + 24
+    d_circ = torch.from_numpy(np.asarray(circ, np.int32)).to(dev)
+    d_blob = torch.zeros(off + 64, dtype=torch.uint8, device=dev)
+    d_blob[:sum(d.size for d in descs)] = torch.from_numpy(np.concatenate(descs)).to(dev)
+    d_lj = torch.from_numpy(np.frombuffer(bytes(lj), np.uint8).copy()).to(dev)
+    d_dj = torch.from_numpy(np.frombuffer(bytes(dj), np.uint8).copy()).to(dev)
+    d_res = torch.zeros(nfr * nline * 28, dtype=torch.uint8, device=dev)
+    ms = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_disc_masks_d(ctx.handle, P(d_circ), len(circ), P(d_dj), nfr * nline,
+                                                                               P(d_blob), off, None, 2400)))
+    out["disc_masks_3072x60x40"] = {"ms": ms, "alg_bytes": alg_disc, "GB/s": alg_disc / (ms * 1e-3) / 1e9, "frac_hbm": alg_disc / (ms * 1e-3) / 8e12}
+    ms = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_line_track_batch_d(ctx.handle, pyr.handle, P(d_lj), nfr * nline, P(d_blob),
+                                                                                     off, P(d_res))))
+    res = d_res.cpu().numpy().view(np.int32).reshape(-1, 7)
+    # cells per line: the coarsest level evaluates every interior cell of the 60x40 area (no patch mask), level 0 a 5x5 window
+    cells = 60 * 40 + 25
+    out["line_track_3072x81x81"] = {"ms": ms, "lines": nfr * nline, "refined": float((res[:, 5] == 2).mean()),
+                                    "positions/s": cells * nfr * nline / (ms * 1e-3),
+                                    "u8_mac/s": (60 * 40 * 40 * 40 + 25 * 81 * 81) * 2.0 * nfr * nline / (ms * 1e-3)}
+    pyr.close()
     print(json.dumps(out, indent=1))
     ctx.close()
 

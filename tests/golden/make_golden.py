@@ -77,6 +77,36 @@ def fast_frames(seed=synth.SEED_BASE + 4):
     return [synth.frame(640, 360, seed + i, (13 * i, 7 * i)) for i in range(2)]
 
 
+def project_case(seed=synth.SEED_BASE + 21, n=16, dsize=21):
+    """Seeded Feature::project / Feature::track inputs: one camera, n slanted planar features."""
+    rng = np.random.default_rng(seed)
+    w, h, shift = 640, 480, (2, -3)
+    f0, f1 = synth.frame(w, h, seed), synth.frame(w, h, seed, shift)
+    P = synth.camera(w, h, rng)
+    feats = []
+    for (cx, cy) in synth.feature_grid(w, h, n, dsize + 30, rng):
+        B, p3d, p2d = synth.plane_feature(P, cx, cy, rng)
+        feats.append(dict(frame=0, descriptor=synth.cut_template(f0, cx, cy, dsize, dsize), P=P, B=B, p3d=p3d,
+                          px=float(p2d[0]) - shift[0] + 1.25, py=float(p2d[1]) - shift[1] - 0.5, threshold=0.9, stride=3))
+    return dict(frame=f1, subs=[1.0, 3.0], feats=feats)
+
+
+def line_case(seed=synth.SEED_BASE + 22, n=8, half=20):
+    """Seeded LineFeature::track inputs: descriptors, area rectangles and circle lists on the coarsest level."""
+    rng = np.random.default_rng(seed)
+    w, h, shift, subs = 640, 480, (-3, 2), [1.0, 2.0]
+    f0, f1 = synth.frame(w, h, seed), synth.frame(w, h, seed, shift)
+    jobs = []
+    for (cx, cy) in synth.feature_grid(w, h, n, half + 40, rng):
+        tx, ty = (cx - shift[0]) // 2, (cy - shift[1]) // 2
+        k = int(rng.integers(3, 8))
+        circ = np.stack([rng.integers(4, 40, k), rng.integers(4, 26, k), rng.integers(1, 7, k)], 1).astype(np.int32)
+        circ[0] = (22, 15, 5)                                   # the disc that holds the true position
+        jobs.append(dict(frame=0, descriptor=synth.cut_template(f0, cx, cy, 2 * half + 1, 2 * half + 1),
+                         area=(int(tx) - 22, int(ty) - 15, 44, 30), circles=circ, threshold=0.9, stride=2))
+    return dict(frame=f1, subs=subs, jobs=jobs)
+
+
 def main():
     O.build()
     out = {}
@@ -106,6 +136,30 @@ def main():
     ramp6 = (np.arange(36, dtype=np.uint8) * 5).reshape(6, 6)
     out["kat/resize_4x4_by2"] = O.resize(ramp4, 2, 2)
     out["kat/resize_6x6_by3"] = O.resize(ramp6, 2, 2)
+    pc = project_case()
+    levels = O.pyramid(pc["frame"], pc["subs"])
+    locs, crcs, tr = [], [], []
+    for f in pc["feats"]:
+        proj, mask, loc = O.project(f["descriptor"], f["P"], f["B"], f["p3d"])
+        locs.append(loc); crcs.append((crc(proj), crc(mask)))
+        r = O.track(levels, pc["subs"], proj, mask, f["px"], f["py"], f["threshold"], f["stride"])
+        tr.append((r["x"], r["y"], r["levels_run"], int(np.float32(r["response"]).view(np.uint32))))
+    out["project/loc"] = np.array(locs, np.int32)
+    out["project/crc"] = np.array(crcs, np.uint32)
+    out["project/track"] = np.array(tr, np.int64)
+    lc = line_case()
+    levels = O.pyramid(lc["frame"], lc["subs"])
+    lt, mc = [], []
+    for j in lc["jobs"]:
+        am = O.disc_mask(j["area"][2], j["area"][3], j["circles"])
+        mc.append(crc(am))
+        r = O.line_track(levels, lc["subs"], j["descriptor"], j["area"], am, j["threshold"], j["stride"])
+        lt.append((r["x"], r["y"], r["levels_run"], int(np.float32(r["response"]).view(np.uint32))))
+    out["line/mask_crc"] = np.array(mc, np.uint32)
+    out["line/track"] = np.array(lt, np.int64)
+    f = fast_frames()[0]
+    srt = O.sort_keypoints(O.fast(f, 20, True))
+    out["newpoints/sel"] = O.select_new_points(srt, np.array([[100, 100], [320, 180]], np.float32), 40, 30.0, 10, 10, f.shape[1], f.shape[0])
     np.savez_compressed(os.path.join(HERE, "golden_r01.npz"), **out)
     print("wrote", os.path.join(HERE, "golden_r01.npz"), len(out), "arrays")
 

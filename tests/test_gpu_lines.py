@@ -112,3 +112,39 @@ def test_line_track_matches_oracle(ctx, oracle, subs, half, n):
         full += r["levels_run"] == len(subs)
     assert full >= n // 2
     assert got[-2]["response"] == -1.0 and (got[-2]["x"], got[-2]["y"]) == (0, 0)
+
+
+def test_golden_projection_line_newpoint_vectors_on_gpu(ctx):
+    """The committed vectors for Feature::project + track, the line masks and walks and the new-point selection
+    (tests/golden/make_golden.py), reproduced by the HIP path without the oracle in the loop."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden as MG
+    gold = np.load(os.path.join(here, "golden", "golden_r01.npz"))
+    pc = MG.project_case()
+    pyr = api.ImagePyramid(ctx, pc["frame"], pc["subs"])
+    try:
+        res = api.project_track_batch(ctx, pyr, pc["feats"])
+    finally:
+        pyr.close()
+    for i, (f, r) in enumerate(zip(pc["feats"], res)):
+        proj, mask, loc = api.project(ctx, f["descriptor"], f["P"], f["B"], f["p3d"])
+        assert list(loc) == gold["project/loc"][i].tolist()
+        assert [MG.crc(proj), MG.crc(mask)] == gold["project/crc"][i].tolist()
+        assert [r["x"], r["y"], r["levels_run"], int(np.float32(r["response"]).view(np.uint32))] == gold["project/track"][i].tolist()
+    lc = MG.line_case()
+    masks = _disc_masks(ctx, [(j["area"][2], j["area"][3], j["circles"]) for j in lc["jobs"]])
+    assert [MG.crc(m) for m, _ in masks] == gold["line/mask_crc"].tolist()
+    pyr = api.ImagePyramid(ctx, lc["frame"], lc["subs"])
+    try:
+        res = api.match_lines_batch(ctx, pyr, lc["jobs"])
+    finally:
+        pyr.close()
+    got = [[r["x"], r["y"], r["levels_run"], int(np.float32(r["response"]).view(np.uint32))] for r in res]
+    assert got == gold["line/track"].tolist()
+    f = MG.fast_frames()[0]
+    kps = api.fast(ctx, f, 20, True)[0][0]
+    sel = api.add_new_points(ctx, f, kps, np.array([[100, 100], [320, 180]], np.float32), 40, 30.0, 10, 10, want_descriptors=False)["sel"]
+    assert np.array_equal(sel, gold["newpoints/sel"])

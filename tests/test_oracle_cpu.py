@@ -258,3 +258,37 @@ def test_project_setup_known_answers_and_library_agreement(oracle):
         assert np.array_equal(got["m"].view(np.uint32), ref["m"].view(np.uint32)), i
         nvalid += ref["valid"]
     assert 150 < nvalid < 400
+
+
+def test_oracle_matches_golden_projection_line_newpoint_vectors(oracle):
+    gold = np.load(GOLD)
+    pc = MG.project_case()
+    levels = oracle.pyramid(pc["frame"], pc["subs"])
+    for i, f in enumerate(pc["feats"]):
+        proj, mask, loc = oracle.project(f["descriptor"], f["P"], f["B"], f["p3d"])
+        assert list(loc) == gold["project/loc"][i].tolist()
+        assert [MG.crc(proj), MG.crc(mask)] == gold["project/crc"][i].tolist()
+        r = oracle.track(levels, pc["subs"], proj, mask, f["px"], f["py"], f["threshold"], f["stride"])
+        assert [r["x"], r["y"], r["levels_run"], int(np.float32(r["response"]).view(np.uint32))] == gold["project/track"][i].tolist()
+    lc = MG.line_case()
+    levels = oracle.pyramid(lc["frame"], lc["subs"])
+    for i, j in enumerate(lc["jobs"]):
+        am = oracle.disc_mask(j["area"][2], j["area"][3], j["circles"])
+        assert MG.crc(am) == gold["line/mask_crc"][i]
+        r = oracle.line_track(levels, lc["subs"], j["descriptor"], j["area"], am, j["threshold"], j["stride"])
+        assert [r["x"], r["y"], r["levels_run"], int(np.float32(r["response"]).view(np.uint32))] == gold["line/track"][i].tolist()
+    f = MG.fast_frames()[0]
+    srt = oracle.sort_keypoints(oracle.fast(f, 20, True))
+    sel = oracle.select_new_points(srt, np.array([[100, 100], [320, 180]], np.float32), 40, 30.0, 10, 10, f.shape[1], f.shape[0])
+    assert np.array_equal(sel, gold["newpoints/sel"])
+
+
+def test_disc_mask_is_the_euclidean_disc(oracle):
+    """The restated cv::circle walk fills exactly (x-cx)^2 + (y-cy)^2 <= r^2 — what the device kernel tests."""
+    for r in list(range(0, 70)) + [100, 151, 300]:
+        n = 2 * r + 5
+        y, x = np.mgrid[0:n, 0:n]
+        assert np.array_equal(oracle.disc_mask(n, n, [[r + 2, r + 2, r]]), (((x - r - 2) ** 2 + (y - r - 2) ** 2 <= r * r) * 255).astype(np.uint8)), r
+    m = oracle.disc_mask(20, 10, [[-3, 4, 6], [25, 5, 7]])        # clipped at both sides
+    y, x = np.mgrid[0:10, 0:20]
+    assert np.array_equal(m > 0, ((x + 3) ** 2 + (y - 4) ** 2 <= 36) | ((x - 25) ** 2 + (y - 5) ** 2 <= 49))
