@@ -160,6 +160,52 @@ def oracle_run_parallel(frames, jobs, blob, nfr, nproc):
     return wall, sum(r[1] for r in res)
 
 
+def fast_leg(api, capi, ctx, stream, dev, args):
+    """FAST-9-16 + NMS px/s on C4 (BASELINE.json configs[3]): 64 frames 1920x1080 resident in HBM, threshold 10
+    (SLAM::fastThreshold's initial value, SLAM.hpp:177); frame 0's corner list is compared with the oracle's first."""
+    import torch
+    from slam_amd import synth
+    w, h, nfr, cap, thr = 1920, 1080, 64, 262144, 10
+    base = np.stack([synth.frame(w, h, 0x51A40004 + i) for i in range(4)])
+    d = torch.from_numpy(base).to(dev).repeat(nfr // 4, 1, 1).contiguous()
+    L = capi.lib()
+    sb = L.slam_hip_fast_scratch_bytes(w, h, nfr, cap)
+    d_scr = torch.zeros(sb, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(nfr * cap * 12, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(nfr, dtype=torch.int32, device=dev)
+
+    def go():
+        capi.check(ctx.handle, L.slam_hip_fast_detect_d(ctx.handle, C.c_void_p(d.data_ptr()), w, h, w, w * h, nfr, thr, 1,
+                                                        C.c_void_p(d_out.data_ptr()), cap, C.c_void_p(d_cnt.data_ptr()),
+                                                        C.c_void_p(d_scr.data_ptr()), sb))
+    go()
+    torch.cuda.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    parity = None
+    if not args.no_cpu:
+        from oracle import pyoracle as O
+        ref = O.fast(base[0], thr, True)
+        got = d_out[:cap * 12].cpu().numpy().view(np.float32).reshape(cap, 3)[:min(int(cnt[0]), cap)]
+        if len(ref) != cnt[0] or not np.array_equal(got, ref[:cap]):
+            raise SystemExit("PARITY FAILURE: FAST corner list of frame 0 differs from the oracle's")
+        parity = "frame 0: %d corners, list identical to the oracle's" % len(ref)
+    steps = max(5, args.steps)
+    for _ in range(3):
+        go()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in evs:
+        a.record(stream); go(); b.record(stream)
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    alg = w * h * nfr + 12 * int(np.minimum(cnt, cap).sum())
+    return {"workload": "C4: %d frames %dx%d, FAST-9-16 threshold %d + non-max suppression" % (nfr, w, h, thr),
+            "value": w * h * nfr / (ms * 1e-3), "unit": "px/s", "ms": ms, "corners_per_frame": float(cnt.mean()),
+            "roofline": {"bound": "hbm", "kernel": "fast_band_kernel+fast_gather_kernel", "achieved": alg / (ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": alg},
+            "parity": parity}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +215,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=1024, help="frames of the CPU-baseline sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat the CPU sample until this much CPU time")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-fast", action="store_true", help="skip the FAST (C4) leg")
     ap.add_argument("--cpu-procs", type=int, default=16,
                     help="worker processes of the additional all-cores CPU figure (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -220,6 +267,8 @@ def main():
     def step(ev=None):
         if h_frames is not None:
             d_frames.copy_(h_frames, non_blocking=True)
+        if ev is not None:
+            ev[2].record(stream)
         pyr.rebuild_d(d_frames.data_ptr(), W, W * H)
         if ev is not None:
             ev[0].record(stream)
@@ -269,7 +318,7 @@ def main():
     # ---- timing --------------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -283,9 +332,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    pyr_ms = float(np.mean([e[2].elapsed_time(e[0]) for e in evs]))
+    pyr_bytes = nframes * (W * H + sum(pyr.level(i).w * pyr.level(i).h for i in range(1, len(SUBS))))
     tot_pos = float(positions)
     elapsed, tot_pos = parallel.reduce_max_sum(elapsed, tot_pos, rdev)
+    fast = fast_leg(api, capi, ctx, stream, dev, args) if (rank == 0 and not args.no_fast) else None
 
     if rank == 0:
         traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
@@ -314,6 +366,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                          "u8_mac_per_s": macs / (kern_ms * 1e-3), "frac_of_packed_dot_peak": macs / (kern_ms * 1e-3) / DOT4_PEAK_MACS},
             "cpu_baseline": cpu,
+            # the other two kernels BASELINE.json's metric names, measured in the same run (outside the timed steps)
+            "pyramid": {"kernel": "pyr_build_kernel", "ms": pyr_ms, "achieved": pyr_bytes / (pyr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": pyr_bytes},
+            "fast": fast,
         }
         print(json.dumps(line))
     pyr.close()
