@@ -22,7 +22,10 @@ namespace {
 constexpr int FAST_WG = 256;
 constexpr int FAST_CHUNK = 256;                 // pixels per chunk: 4 per lane
 constexpr int FAST_PPITCH = FAST_CHUNK + 8;     // pixel tile pitch: 4 halo columns each side
-constexpr int FAST_LDS_BUDGET = 40 * 1024;
+#ifndef FAST_LDS_BUDGET_KB
+#define FAST_LDS_BUDGET_KB 40
+#endif
+constexpr int FAST_LDS_BUDGET = FAST_LDS_BUDGET_KB * 1024;
 constexpr int FAST_CL_CAP = 1024;               // corners a band can list for the sparse non-max pass
 
 struct FastPlan {
@@ -33,10 +36,10 @@ struct FastPlan {
 };
 
 __host__ __device__ inline size_t fast_lds_bytes(int R, int spitch) {
-    // score tile + pixel chunk + candidate lists (4 wavefronts x up to 8 rows x 256 slots x 2 bytes);
+    // score tile + pixel chunk + candidate lists (4 wavefronts x (R+2)/4 score rows x 256 slots x 2 bytes);
     // phase 3 reuses the pixel chunk + lists as one keep-flag byte per 4 pixels (R * spitch / 4 bytes)
     // a list of the band's corners (FAST_CL_CAP dwords) follows
-    const size_t work = (size_t)(R + 8) * FAST_PPITCH + 4 * 8 * 256 * 2;
+    const size_t work = (size_t)(R + 8) * FAST_PPITCH + (size_t)(R + 2) * 256 * 2;
     const size_t flags = (size_t)R * (spitch / 4);
     return (size_t)(R + 2) * spitch + ((work > flags ? work : flags) + 15) / 16 * 16 + 16 + (size_t)FAST_CL_CAP * 4;
 }
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
     __shared__ int pool_off;
     fl_u8* sc = (fl_u8*)smem;                                    // (R+2) x spitch stored scores; column x at byte x + 4
     fl_u8* px = sc + (size_t)(R + 2) * spitch;                   // (R+8) x FAST_PPITCH pixels of the current chunk
-    fl_u16* lists = (fl_u16*)(px + (size_t)(R + 8) * FAST_PPITCH);   // 4 x (8 rows x 256) candidate slots
-    const size_t work_bytes = (size_t)(R + 8) * FAST_PPITCH + 4 * 8 * 256 * 2, flag_bytes = (size_t)R * (spitch / 4);
+    fl_u16* lists = (fl_u16*)(px + (size_t)(R + 8) * FAST_PPITCH);   // 4 x ((R+2)/4 rows x 256) candidate slots
+    const size_t work_bytes = (size_t)(R + 8) * FAST_PPITCH + (size_t)(R + 2) * 256 * 2, flag_bytes = (size_t)R * (spitch / 4);
     fl_u32* ccount = (fl_u32*)(px + ((work_bytes > flag_bytes ? work_bytes : flag_bytes) + 15) / 16 * 16);
     fl_u32* clist = ccount + 4;                                   // corners of band rows: (band row << 16) | column
 
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
 
     const int srows = R + 2;                                     // score rows: image rows y0-1 .. y0+R
     const int rows_per_wave = srows >> 2;
-    fl_u16* mylist = lists + wid * (8 * 256);
+    fl_u16* mylist = lists + wid * (rows_per_wave * 256);
     for (int cx = 0; cx < w; cx += FAST_CHUNK) {
         __syncthreads();                                         // previous chunk's readers are done (and the zeroing)
         // ---- stage pixels: tile row r <-> image row y0 - 4 + r, tile byte c <-> image column cx - 4 + c
