@@ -181,10 +181,13 @@ typedef struct slam_keypoint {
     float response;     /* corner score */
 } slam_keypoint;
 
-/* Scratch bytes slam_hip_fast_detect_d needs for this shape (device memory, caller-allocated). */
+/* Scratch bytes slam_hip_fast_detect_d needs for this shape (device memory, caller-allocated, 16-byte
+ * aligned): about 2 bytes per pixel - a fixed segment of 16-bit keys per (row, 248-column tile) plus
+ * two count tables; it does not depend on cap_per_frame. */
 size_t slam_hip_fast_scratch_bytes(int w, int h, int nframes, int cap_per_frame);
 /* Device frames, asynchronous.  d_out holds nframes*cap_per_frame keypoints, d_counts nframes
- * ints (the number FOUND per frame; when it exceeds cap_per_frame the frame's list is truncated). */
+ * ints (the number FOUND per frame; when it exceeds cap_per_frame the frame's list is its first
+ * cap_per_frame keypoints in row-major order). */
 int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, int w, int h, size_t pitch,
                            size_t frame_stride, int nframes, int threshold, int nonmax,
                            slam_keypoint* d_out, int cap_per_frame, int32_t* d_counts,

@@ -18,6 +18,11 @@ __global__ void k(unsigned* out, int iters) {
                 if (MODE == 2) a[i] = (a[i] & b) | (c & ~b);
                 if (MODE == 3) a[i] = a[i] * 3u + b;   // v_mad_u32_u24 / v_mul_lo
                 if (MODE == 4) a[i] = __builtin_amdgcn_udot4(a[i], a[i], c, false);
+                if (MODE == 5) { typedef unsigned short u2 __attribute__((ext_vector_type(2)));      // v_pk_max_u16
+                                 a[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u2, a[i]), __builtin_bit_cast(u2, b))); }
+                if (MODE == 6) a[i] = max(a[i], (b >> 8) & 0xffu);     // v_max_u32_sdwa (byte select of one operand)
+                if (MODE == 7) a[i] = max(a[i], b);                     // v_max_u32
+                if (MODE == 8) a[i] = max(max(a[i], b), c);             // v_max3_u32
             }
         }
         b += 7; c ^= b;
@@ -57,6 +62,10 @@ int main() {
         run<1>("v_perm_b32", d, w);
         run<2>("v_bfi_b32", d, w);
         run<3>("v_mad (u32 mul-add)", d, w);
+        run<5>("v_pk_max_u16", d, w);
+        run<6>("v_max_u32_sdwa", d, w);
+        run<7>("v_max_u32", d, w);
+        run<8>("v_max3_u32", d, w);
     }
     return 0;
 }

@@ -1,17 +1,19 @@
 // FAST-9-16 corner score + non-max suppression (cv::FAST as called at new_point.cpp:120) and
 // SLAM::getSortedKeyPoints (new_point.cpp:113-127).
 //
-// Kernel 1 (fast_band_kernel): one workgroup (4 wavefronts) per band of R image rows of one frame.
-//   Phase 1+2, per 256-pixel chunk of the band: the chunk's pixels (+ halo) are staged into LDS; each
-//   lane tests 4 adjacent pixels with the opposite-pair test (a 9-long arc contains one pixel of
-//   every opposite ring pair, so "all 8 pairs have a brighter / darker member" is necessary), the
-//   wavefront compacts the candidates and computes the exact score only for those, writing the
-//   stored score (score for corners, 0 otherwise) of band rows -1..R into an LDS score tile.
-//   Phase 3: each wavefront walks its rows of the score tile in row-major order, applies the strict
-//   3x3 non-max test to the non-zero entries and compacts survivors with ballots; a first pass
-//   counts, the band reserves a slice of the frame's key pool, a second pass writes the keys.
-// Kernel 2 (fast_gather_kernel): one workgroup per frame concatenates the bands in band order,
-//   which gives cv::FAST's row-major keypoint order, and converts keys to keypoints.
+// Kernel 1 (fast_tile_kernel): one workgroup (4 wavefronts) per tile of 248 x 30 output pixels of one
+//   frame.  The tile's pixels (+ 4-pixel halo) are staged into LDS once.
+//   Phase 1: each lane tests 4 adjacent pixels with the opposite-pair test (a 9-long arc contains one
+//   pixel of every opposite ring pair, so "all 8 pairs have a brighter / darker member" is necessary)
+//   and the wavefront compacts the candidates of 4 score rows at a time into a list.
+//   Phase 2: one lane per listed candidate computes the exact score; the stored score (score for
+//   corners, 0 otherwise) of tile rows -1..30 and columns -4..251 goes into an LDS score tile.
+//   Phase 3: each wavefront walks its output rows, applies the strict 3x3 non-max test and compacts the
+//   survivors of a row with ballots into that (row, tile) segment of the frame's key table; the
+//   segment's length goes into a count table.  No atomics: every segment has a fixed place.
+// Kernel 2 (fast_scan_kernel): one workgroup per frame turns the (row, tile) counts into offsets in
+//   row-major order - cv::FAST's keypoint order - and reports the frame's total.
+// Kernel 3 (fast_scatter_kernel): copies every segment to its place in the output as keypoints.
 #include <algorithm>
 #include <cmath>
 
@@ -20,46 +22,31 @@
 namespace {
 
 constexpr int FAST_WG = 256;
-constexpr int FAST_CHUNK = 256;                 // pixels per chunk: 4 per lane
-constexpr int FAST_PPITCH = FAST_CHUNK + 8;     // pixel tile pitch: 4 halo columns each side
-#ifndef FAST_LDS_BUDGET_KB
-#define FAST_LDS_BUDGET_KB 40
-#endif
-constexpr int FAST_LDS_BUDGET = FAST_LDS_BUDGET_KB * 1024;
-constexpr int FAST_CL_CAP = 1024;               // corners a band can list for the sparse non-max pass
+constexpr int FAST_TW = 248;                    // output columns per tile
+constexpr int FAST_CW = 256;                    // columns with a stored score: 4 halo columns each side (4 pixels per lane)
+constexpr int FAST_PPITCH = FAST_CW + 8;        // pixel tile pitch: 4 more columns each side for the ring
+constexpr int FAST_TH = 30;                     // output rows per tile
+constexpr int FAST_SR = FAST_TH + 2;            // score rows: one halo row above and below; 8 per wavefront
+constexpr int FAST_PR = FAST_TH + 8;            // pixel rows
+constexpr int FAST_HALF = FAST_SR / 8;          // score rows a wavefront tests before it scores their candidates
+constexpr int FAST_LIST = FAST_HALF * FAST_CW;  // candidate slots per wavefront
 
 struct FastPlan {
-    int R;            // rows per band; R + 2 score rows are a multiple of 4 (one share per wavefront)
-    int nbands;
-    int spitch;       // score tile pitch (bytes): 4 + w + 4, rounded up to 4
-    size_t lds_bytes;
+    int ntx, nty;     // tiles per row / column of tiles
 };
 
-__host__ __device__ inline size_t fast_lds_bytes(int R, int spitch) {
-    // score tile + pixel chunk + candidate lists (4 wavefronts x (R+2)/4 score rows x 256 slots x 2 bytes);
-    // phase 3 reuses the pixel chunk + lists as one keep-flag byte per 4 pixels (R * spitch / 4 bytes)
-    // a list of the band's corners (FAST_CL_CAP dwords) follows
-    const size_t work = (size_t)(R + 8) * FAST_PPITCH + (size_t)(R + 2) * 256 * 2;
-    const size_t flags = (size_t)R * (spitch / 4);
-    return (size_t)(R + 2) * spitch + ((work > flags ? work : flags) + 15) / 16 * 16 + 16 + (size_t)FAST_CL_CAP * 4;
-}
-
 bool fast_plan(int w, int h, FastPlan& p) {
-    const int spitch = (w + 8 + 3) & ~3;
-    for (int R = 30; R >= 2; R -= 4) {
-        if (fast_lds_bytes(R, spitch) <= (size_t)FAST_LDS_BUDGET || R == 2) {
-            if (fast_lds_bytes(R, spitch) > 64 * 1024) return false;   // dynamic LDS of a plain launch
-            p.R = R; p.nbands = (h + R - 1) / R; p.spitch = spitch; p.lds_bytes = fast_lds_bytes(R, spitch);
-            return true;
-        }
-    }
-    return false;
+    if (w < 1 || h < 1 || w > (1 << 16) || h > (1 << 20)) return false;
+    p.ntx = (w + FAST_TW - 1) / FAST_TW;
+    p.nty = (h + FAST_TH - 1) / FAST_TH;
+    return true;
 }
 
-// per-frame scratch layout (all 4-byte words): [0] pool counter, [1..3] pad, then band_off[nbands],
-// band_cnt[nbands], then the key pool of `cap` keys
-__host__ __device__ inline size_t fast_frame_words(int nbands, int cap) {
-    return (size_t)4 + 2 * (size_t)((nbands + 3) / 4 * 4) + (size_t)((cap + 3) / 4 * 4);
+// Per-frame scratch (4-byte words): rowcnt[h * ntx], rowoff[h * ntx], then the key table: one segment of
+// FAST_TW 16-bit keys ((column in tile << 8) | stored score) per (row, tile), rows padded to whole words.
+__host__ __device__ inline size_t fast_tab_words(int h, int ntx) { return ((size_t)h * ntx + 3) / 4 * 4; }
+__host__ __device__ inline size_t fast_frame_words(int h, int ntx) {
+    return 2 * fast_tab_words(h, ntx) + (size_t)h * ntx * (FAST_TW / 2);
 }
 
 typedef __attribute__((address_space(3))) unsigned char fl_u8;
@@ -83,6 +70,17 @@ __device__ __forceinline__ constexpr int ring_dy(int k) {
 }
 
 typedef short fast_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short fast_u2 __attribute__((ext_vector_type(2)));
+
+// Two of a lane's four pixels' ring neighbours as 16-bit halves: window bytes (4 + dx + odd) and
+// (6 + dx + odd) of the 12-byte row window {a, b, c}, picked with one v_perm_b32.
+__device__ __forceinline__ fast_u2 ring_pair(unsigned a, unsigned b, unsigned c, int dx, int odd) {
+    const int i0 = 4 + dx + odd, i2 = i0 + 2;
+    unsigned r;
+    if (i2 <= 7) r = __builtin_amdgcn_perm(b, a, 0x0c000c00u | (unsigned)i0 | ((unsigned)i2 << 16));
+    else r = __builtin_amdgcn_perm(c, b, 0x0c000c00u | (unsigned)(i0 - 4) | ((unsigned)(i2 - 4) << 16));
+    return __builtin_bit_cast(fast_u2, r);
+}
 
 // max over the 16 arcs of 9 contiguous ring pixels of the arc minimum of (v - ring) [low half] and
 // of (ring - v) [high half]: the two "A" values of cv::FAST's cornerScore, by window doubling.
@@ -119,43 +117,35 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
     return v;
 }
 
-__global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
-    const uint8_t* __restrict__ frames, int w, int h, long long pitch, long long frame_stride,
-    int threshold, int nonmax, int R, int spitch, int nbands, int cap, unsigned* __restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int wave_cnt[4];
-    __shared__ int pool_off;
-    fl_u8* sc = (fl_u8*)smem;                                    // (R+2) x spitch stored scores; column x at byte x + 4
-    fl_u8* px = sc + (size_t)(R + 2) * spitch;                   // (R+8) x FAST_PPITCH pixels of the current chunk
-    fl_u16* lists = (fl_u16*)(px + (size_t)(R + 8) * FAST_PPITCH);   // 4 x ((R+2)/4 rows x 256) candidate slots
-    const size_t work_bytes = (size_t)(R + 8) * FAST_PPITCH + (size_t)(R + 2) * 256 * 2, flag_bytes = (size_t)R * (spitch / 4);
-    fl_u32* ccount = (fl_u32*)(px + ((work_bytes > flag_bytes ? work_bytes : flag_bytes) + 15) / 16 * 16);
-    fl_u32* clist = ccount + 4;                                   // corners of band rows: (band row << 16) | column
 
-    const int band = blockIdx.x, frame = blockIdx.y;
+__global__ __launch_bounds__(FAST_WG) void fast_tile_kernel(
+    const uint8_t* __restrict__ frames, int w, int h, long long pitch, long long frame_stride,
+    int threshold, int nonmax, int ntx, unsigned* __restrict__ scratch) {
+    __shared__ __attribute__((aligned(16))) unsigned char px_s[FAST_PR * FAST_PPITCH];    // pixels
+    __shared__ __attribute__((aligned(16))) unsigned char sc_s[FAST_SR * FAST_CW];        // stored scores
+    __shared__ unsigned short lists_s[4 * FAST_LIST];
+    fl_u8* px = (fl_u8*)px_s;
+    fl_u8* sc = (fl_u8*)sc_s;
+    fl_u16* lists = (fl_u16*)lists_s;
+
+    const int tx = blockIdx.x, ty = blockIdx.y, frame = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t* im = frames + (long long)frame * frame_stride;
-    const int y0 = band * R;                                     // first image row of the band
-    unsigned* fs = scratch + (size_t)frame * fast_frame_words(nbands, cap);
+    const int cx0 = tx * FAST_TW, y0 = ty * FAST_TH;            // first output column / row of the tile
+    unsigned* fs = scratch + (size_t)frame * fast_frame_words(h, ntx);
     const bool aligned = ((reinterpret_cast<unsigned long long>(frames) | (unsigned long long)pitch | (unsigned long long)frame_stride) & 3ull) == 0;
     const int t = threshold;
 
-    if (tid == 0) *ccount = 0u;
     {   // zero the score tile
         fl_u32* z = (fl_u32*)sc;
-        const int n = ((R + 2) * spitch) >> 2;
-        for (int i = tid; i < n; i += FAST_WG) z[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < FAST_SR * FAST_CW / 4 / FAST_WG; i++) z[tid + i * FAST_WG] = 0u;
     }
-
-    const int srows = R + 2;                                     // score rows: image rows y0-1 .. y0+R
-    const int rows_per_wave = srows >> 2;
-    fl_u16* mylist = lists + wid * (rows_per_wave * 256);
-    for (int cx = 0; cx < w; cx += FAST_CHUNK) {
-        __syncthreads();                                         // previous chunk's readers are done (and the zeroing)
-        // ---- stage pixels: tile row r <-> image row y0 - 4 + r, tile byte c <-> image column cx - 4 + c
-        // (loads of a batch are all issued before the first LDS write: one memory round trip per batch)
-        constexpr int NB = 6;
-        const int ndw = (R + 8) * (FAST_PPITCH / 4);
+    // ---- stage pixels: tile row r <-> image row y0 - 4 + r, tile byte c <-> image column cx0 - 8 + c
+    // (loads of a batch are all issued before the first LDS write: one memory round trip per batch)
+    {
+        constexpr int NB = 10;
+        constexpr int ndw = FAST_PR * (FAST_PPITCH / 4);
         for (int base = tid; base < ndw; base += FAST_WG * NB) {
             unsigned v[NB];
 #pragma unroll
@@ -164,7 +154,7 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
                 v[u] = 0;
                 if (i < ndw) {
                     const int r = i / (FAST_PPITCH / 4), c = i - r * (FAST_PPITCH / 4);
-                    const int y = y0 - 4 + r, x = cx - 4 + 4 * c;
+                    const int y = y0 - 4 + r, x = cx0 - 8 + 4 * c;
                     if (y >= 0 && y < h && x + 3 >= 0 && x < w) {
                         const uint8_t* src = im + (long long)y * pitch + x;
                         if (aligned && x >= 0 && x + 3 < w) v[u] = *reinterpret_cast<const unsigned*>(src);
@@ -182,273 +172,230 @@ __global__ __launch_bounds__(FAST_WG) void fast_band_kernel(
                 if (i < ndw) reinterpret_cast<fl_u32*>(px)[i] = v[u];
             }
         }
-        __syncthreads();
-        // ---- phase 1 + 2: each wavefront takes rows_per_wave score rows of this chunk
-        int n = 0;                                               // candidates of this wavefront in this chunk
-        for (int rr = 0; rr < rows_per_wave; rr++) {
-            const int ry = wid * rows_per_wave + rr;             // score row; image row y0 - 1 + ry; pixel tile row ry + 3
-            const int y = y0 - 1 + ry;
-            if (y < 3 || y >= h - 3) continue;                   // wave-uniform
-            const int x0 = cx + 4 * lane;                        // first of the lane's 4 pixels
-            unsigned cand = 0;
-#ifdef FAST_DIAG_SKIP_P1
-            if (x0 < -w) {
-#else
-            if (x0 < w) {
-#endif
-                // window rows dy = -3..3: dwords at tile bytes 4*lane, +4, +8 (image columns x0-4 .. x0+7)
-                unsigned A[7], B[7], Cw[7];
-#pragma unroll
-                for (int d = 0; d < 7; d++) {
-                    const fl_u32* row = reinterpret_cast<const fl_u32*>(px + (ry + d) * FAST_PPITCH) + lane;
-                    A[d] = row[0]; B[d] = row[1]; Cw[d] = row[2];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int v = win_byte(A[3], B[3], Cw[3], 4 + j);
-                    // every opposite pair must have a member brighter than v+t (resp. darker than v-t):
-                    // min over pairs of the pair maximum > v+t, max over pairs of the pair minimum < v-t
-                    int mn_of_mx = 255, mx_of_mn = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int r0 = win_byte(A[3 + ring_dy(k)], B[3 + ring_dy(k)], Cw[3 + ring_dy(k)], 4 + j + ring_dx(k));
-                        const int r1 = win_byte(A[3 + ring_dy(k + 8)], B[3 + ring_dy(k + 8)], Cw[3 + ring_dy(k + 8)], 4 + j + ring_dx(k + 8));
-                        mn_of_mx = min(mn_of_mx, max(r0, r1));
-                        mx_of_mn = max(mx_of_mn, min(r0, r1));
-                    }
-                    const bool bright = mn_of_mx > v + t, dark = mx_of_mn < v - t;
-                    const int x = x0 + j;
-                    if ((bright || dark) && x >= 3 && x < w - 3) cand |= 1u << j;
-                }
-            }
-            // append the candidates of these 256 pixels to the wavefront's list: (score row << 8) | column
-            if (__ballot(cand != 0u) != 0ull) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const bool c = (cand >> j) & 1u;
-                    const unsigned long long bal = __ballot(c);
-                    if (c) mylist[n + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((rr << 8) | (4 * lane + j));
-                    n += __popcll(bal);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef FAST_DIAG_SKIP_P2
-        n = 0;
-#endif
-        for (int i = lane; i < n; i += 64) {
-            const int e = mylist[i];
-            const int lx = e & 255, ry = wid * rows_per_wave + (e >> 8);
-            int ad, ab;
-            fast_arc_scores(px + (ry + 3) * FAST_PPITCH + 4 + lx, FAST_PPITCH, ad, ab);
-            const int a = max(ad, ab);
-            if (a > t) {
-                sc[ry * spitch + 4 + cx + lx] = (unsigned char)(nonmax ? a - 1 : a);   // no NMS: score + 1 marks a corner
-                if (ry >= 1 && ry <= R) {                        // halo rows only serve as neighbours
-                    const unsigned pos = __hip_atomic_fetch_add(ccount, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (pos < (unsigned)FAST_CL_CAP) clist[pos] = ((unsigned)(ry - 1) << 16) | (unsigned)(cx + lx);
-                }
-            }
-        }
     }
     __syncthreads();
 
-    // ---- phase 3: non-max suppression and ordered compaction; pass 0 counts, pass 1 writes
-    const int r_lo = (R * wid) >> 2, r_hi = (R * (wid + 1)) >> 2;   // this wavefront's band rows
-    unsigned* pool = fs + 4 + 2 * ((nbands + 3) / 4 * 4);
-    const int ncorner = (int)*ccount;
-    const int wpr = (w + 31) >> 5;                               // bitmap words per row
-    if (ncorner <= FAST_CL_CAP && (size_t)R * wpr * 4 <= work_bytes) {
-        // Sparse band: one lane per listed corner decides the non-max test and sets its bit in a
-        // band bitmap (over the pixel chunk, free now); the bitmap is then read out in row-major order.
-        fl_u32* bmp = (fl_u32*)px;
-        for (int i = tid; i < R * wpr; i += FAST_WG) bmp[i] = 0u;
-        __syncthreads();
-        for (int i = tid; i < ncorner; i += FAST_WG) {
-            const unsigned e = clist[i];
-            const int ry = (int)(e >> 16), x = (int)(e & 0xffffu);
-            const int y = y0 + ry;
-            if (y < 3 || y >= h - 3) continue;
-            const fl_u8* c = sc + (ry + 1) * spitch + 4 + x;
-            bool keep = true;
-            if (nonmax) {
-                const int s0 = c[0];
-                int nb = max(max((int)c[-1], (int)c[1]), max((int)c[-spitch], (int)c[spitch]));
-                nb = max(nb, max(max((int)c[-spitch - 1], (int)c[-spitch + 1]), max((int)c[spitch - 1], (int)c[spitch + 1])));
-                keep = s0 > nb;
-            }
-            if (keep) __hip_atomic_fetch_or(bmp + ry * wpr + (x >> 5), 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        __syncthreads();
-        int cnt = 0;
-        for (int ry = r_lo; ry < r_hi; ry++)
-            for (int wb = 0; wb < wpr; wb += 64)
-                if (wb + lane < wpr) cnt += __popc(bmp[ry * wpr + wb + lane]);
-        {
-            const unsigned tot = wave_scan_incl((unsigned)cnt);
-            if (lane == 63) wave_cnt[wid] = (int)tot;
-        }
-        __syncthreads();
-        const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
-        const int total = c0 + c1 + c2 + c3;
-        if (tid == 0) {
-            int off = 0;
-            if (total > 0) off = (int)atomicAdd(&fs[0], (unsigned)total);
-            pool_off = off;
-            const int nb4 = (nbands + 3) / 4 * 4;
-            fs[4 + band] = (unsigned)off;
-            fs[4 + nb4 + band] = (unsigned)total;
-        }
-        __syncthreads();
-        if (total == 0) return;
-        int pos0 = pool_off + ((wid == 0) ? 0 : (wid == 1) ? c0 : (wid == 2) ? c0 + c1 : c0 + c1 + c2);
-        for (int ry = r_lo; ry < r_hi; ry++)
-            for (int wb = 0; wb < wpr; wb += 64) {
-                unsigned m = (wb + lane < wpr) ? bmp[ry * wpr + wb + lane] : 0u;
-                const unsigned incl = wave_scan_incl((unsigned)__popc(m));
-                int pos = pos0 + (int)incl - __popc(m);
-                pos0 += (int)__builtin_amdgcn_readlane((int)incl, 63);
-                while (m) {
-                    const int b = __ffs((int)m) - 1;
-                    m &= m - 1u;
-                    const int x = ((wb + lane) << 5) + b;
-                    const unsigned s = sc[(ry + 1) * spitch + 4 + x];
-                    if (pos < cap) pool[pos] = ((unsigned)(ry * w + x) << 8) | (nonmax ? s : s - 1u);
-                    pos++;
-                }
-            }
-        return;
-    }
-    fl_u8* flags = px;                                           // the pixel chunk and the lists are free now
-    const int fpitch = spitch >> 2;
-    int base = 0;
-#ifdef FAST_DIAG_SKIP_P3
-    if (w > 0) return;
+    // ---- phase 1: the wavefront's 8 score rows; score row ry <-> image row y0 - 1 + ry <-> pixel row ry + 3;
+    // score column c <-> image column cx0 - 4 + c <-> pixel byte c + 4
+    constexpr int rows_per_wave = FAST_SR / 4;
+    fl_u16* mylist = lists + wid * FAST_LIST;
+    for (int half = 0; half < rows_per_wave; half += FAST_HALF) {
+    int n = 0;                                                   // candidates of this wavefront in these rows
+    for (int rr = half; rr < half + FAST_HALF; rr++) {
+        const int ry = wid * rows_per_wave + rr;
+        const int y = y0 - 1 + ry;
+        if (y < 3 || y >= h - 3) continue;                       // wave-uniform
+        const int x0 = cx0 - 4 + 4 * lane;                       // image column of the first of the lane's 4 pixels
+        unsigned cand = 0;
+#ifdef FAST_DIAG_SKIP_P1
+        if (x0 < -w) {
+#else
+        if (x0 < w - 3 && x0 + 3 >= 3) {
 #endif
-    for (int pass = 0; pass < 2; pass++) {
-        int cnt = 0;
-        for (int ry = r_lo; ry < r_hi; ry++) {
-            const int y = y0 + ry;
-            if (y < 3 || y >= h - 3) continue;                   // wave-uniform
-            const fl_u8* row = sc + (ry + 1) * spitch + 4;       // score row of image row y, column 0
-            for (int xb = 0; xb < w; xb += FAST_CHUNK) {
-                const int x0 = xb + 4 * lane;
-                fl_u8* flag = flags + ry * fpitch + (x0 >> 2);   // pass 0 leaves the lane's 4 keep bits here
-                unsigned c4 = 0, keep = 0;
-                if (pass == 1) {
-                    if (x0 < w) keep = *flag;
-                    if (__ballot(keep != 0u) == 0ull) continue;
-                    if (keep) c4 = *reinterpret_cast<const fl_u32*>(row + x0);
-                } else {
-                    if (x0 < w) c4 = *reinterpret_cast<const fl_u32*>(row + x0);
-                    if (__ballot(c4 != 0u) == 0ull) {
-                        if (x0 < w) *flag = 0;
-                        continue;
-                    }
-                    if (c4 != 0u) {
-                        if (nonmax) {
-                            unsigned U[3], M[3], D[3];
+            // window rows dy = -3..3: dwords at pixel bytes 4*lane, +4, +8 (score columns 4*lane-4 .. 4*lane+7)
+            unsigned A[7], B[7], Cw[7];
 #pragma unroll
-                            for (int q = 0; q < 3; q++) {
-                                U[q] = *reinterpret_cast<const fl_u32*>(row - spitch + x0 - 4 + 4 * q);
-                                M[q] = *reinterpret_cast<const fl_u32*>(row + x0 - 4 + 4 * q);
-                                D[q] = *reinterpret_cast<const fl_u32*>(row + spitch + x0 - 4 + 4 * q);
-                            }
+            for (int d = 0; d < 7; d++) {
+                const fl_u32* row = reinterpret_cast<const fl_u32*>(px + (ry + d) * FAST_PPITCH) + lane;
+                A[d] = row[0]; B[d] = row[1]; Cw[d] = row[2];
+            }
+            // Two pixels per operation: E holds pixels j = 0 and 2 as 16-bit halves, O pixels 1 and 3.
+            // Every opposite ring pair must have a member brighter than v+t (resp. darker than v-t):
+            // min over pairs of the pair maximum > v+t, max over pairs of the pair minimum < v-t.
+            fast_u2 mn_of_mx[2], mx_of_mn[2];
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const int s = win_byte(M[0], M[1], M[2], 4 + j);
-                                int nb = 0;                      // largest of the 8 neighbours
+            for (int k = 0; k < 8; k++) {
 #pragma unroll
-                                for (int dx = -1; dx <= 1; dx++) {
-                                    nb = max(nb, max(win_byte(U[0], U[1], U[2], 4 + j + dx), win_byte(D[0], D[1], D[2], 4 + j + dx)));
-                                    if (dx != 0) nb = max(nb, win_byte(M[0], M[1], M[2], 4 + j + dx));
-                                }
-                                if (s > nb) keep |= 1u << j;
-                            }
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; j++)
-                                if ((c4 >> (8 * j)) & 0xffu) keep |= 1u << j;
-                        }
-                    }
-                    if (x0 < w) *flag = (unsigned char)keep;
+                for (int o = 0; o < 2; o++) {
+                    const fast_u2 r0 = ring_pair(A[3 + ring_dy(k)], B[3 + ring_dy(k)], Cw[3 + ring_dy(k)], ring_dx(k), o);
+                    const fast_u2 r1 = ring_pair(A[3 + ring_dy(k + 8)], B[3 + ring_dy(k + 8)], Cw[3 + ring_dy(k + 8)], ring_dx(k + 8), o);
+                    const fast_u2 mx = __builtin_elementwise_max(r0, r1), mn = __builtin_elementwise_min(r0, r1);
+                    mn_of_mx[o] = k == 0 ? mx : __builtin_elementwise_min(mn_of_mx[o], mx);
+                    mx_of_mn[o] = k == 0 ? mn : __builtin_elementwise_max(mx_of_mn[o], mn);
                 }
-                // row-major order inside the chunk = lane-major, then j
-                int before = 0, total = 0;
+            }
+            const fast_u2 T = fast_u2{(unsigned short)t, (unsigned short)t};
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const fast_u2 v = ring_pair(A[3], B[3], Cw[3], 0, o);
+                // bright: mn_of_mx > v + t; dark: mx_of_mn + t < v (saturating differences are non-zero exactly then)
+                const fast_u2 hit = __builtin_elementwise_sub_sat(mn_of_mx[o], v + T) | __builtin_elementwise_sub_sat(v, mx_of_mn[o] + T);
+                if (hit.x != 0) cand |= 1u << o;
+                if (hit.y != 0) cand |= 4u << o;
+            }
+            // only pixels with a full ring inside the image are tested (3 <= x < w - 3)
+            unsigned inside = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x0 + j >= 3 && x0 + j < w - 3) inside |= 1u << j;
+            cand &= inside;
+        }
+        // append the candidates of these 256 pixels to the wavefront's list: (row in share << 8) | score column
+        if (__ballot(cand != 0u) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool c = (cand >> j) & 1u;
+                const unsigned long long bal = __ballot(c);
+                if (c) mylist[n + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((rr << 8) | (4 * lane + j));
+                n += __popcll(bal);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef FAST_DIAG_SKIP_P2
+    n = 0;
+#endif
+    // ---- phase 2: exact score of the listed candidates, one lane each
+    for (int i = lane; i < n; i += 64) {
+        const int e = mylist[i];
+        const int c = e & 255, ry = wid * rows_per_wave + (e >> 8);
+        int ad, ab;
+        fast_arc_scores(px + (ry + 3) * FAST_PPITCH + 4 + c, FAST_PPITCH, ad, ab);
+        const int a = max(ad, ab);
+        if (a > t) sc[ry * FAST_CW + c] = (unsigned char)(nonmax ? a - 1 : a);   // no NMS: score + 1 marks a corner
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the list is reused by the next rows
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __syncthreads();
+
+    // ---- phase 3: non-max suppression; every (row, tile) segment is compacted in column order
+    const int nseg = h * ntx;
+    unsigned* rowcnt = fs;
+    unsigned short* keys = reinterpret_cast<unsigned short*>(fs + 2 * fast_tab_words(h, ntx));
+    const int r_lo = (FAST_TH * wid) >> 2, r_hi = (FAST_TH * (wid + 1)) >> 2;   // this wavefront's output rows
+    for (int ro = r_lo; ro < r_hi; ro++) {
+        const int y = y0 + ro;
+        if (y >= h) break;                                       // wave-uniform
+        const int seg = y * ntx + tx;
+        int total = 0;
+#ifdef FAST_DIAG_SKIP_P3
+        if (y < -h) {
+#else
+        if (y >= 3 && y < h - 3) {
+#endif
+            const fl_u8* row = sc + (ro + 1) * FAST_CW;          // score row of image row y
+            const unsigned c4 = (lane >= 1 && lane <= FAST_TW / 4) ? *reinterpret_cast<const fl_u32*>(row + 4 * lane) : 0u;
+            if (__ballot(c4 != 0u) != 0ull) {
+                unsigned keep = 0;
+                if (c4 != 0u) {
+                    if (nonmax) {
+                        unsigned U[3], M[3], D[3];
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            U[q] = *reinterpret_cast<const fl_u32*>(row - FAST_CW + 4 * lane - 4 + 4 * q);
+                            M[q] = *reinterpret_cast<const fl_u32*>(row + 4 * lane - 4 + 4 * q);
+                            D[q] = *reinterpret_cast<const fl_u32*>(row + FAST_CW + 4 * lane - 4 + 4 * q);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int s = win_byte(M[0], M[1], M[2], 4 + j);
+                            int nb = 0;                          // largest of the 8 neighbours
+#pragma unroll
+                            for (int dx = -1; dx <= 1; dx++) {
+                                nb = max(nb, max(win_byte(U[0], U[1], U[2], 4 + j + dx), win_byte(D[0], D[1], D[2], 4 + j + dx)));
+                                if (dx != 0) nb = max(nb, win_byte(M[0], M[1], M[2], 4 + j + dx));
+                            }
+                            if (s > nb) keep |= 1u << j;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if ((c4 >> (8 * j)) & 0xffu) keep |= 1u << j;
+                    }
+                }
+                // column order inside the row = lane-major, then j
+                int before = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const unsigned long long bal = __ballot((keep >> j) & 1u);
                     before += __popcll(bal & ((1ull << lane) - 1ull));
                     total += __popcll(bal);
                 }
-                if (pass == 1 && keep) {
-                    int pos = base + cnt + before;
+                if (keep) {
+                    unsigned short* kseg = keys + (size_t)seg * FAST_TW;
+                    int pos = before;
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if ((keep >> j) & 1u) {
                             const unsigned s = (c4 >> (8 * j)) & 0xffu;
-                            if (pos < cap) pool[pos] = ((unsigned)(ry * w + x0 + j) << 8) | (nonmax ? s : s - 1u);
-                            pos++;
+                            kseg[pos++] = (unsigned short)(((unsigned)(4 * lane - 4 + j) << 8) | (nonmax ? s : s - 1u));
                         }
                 }
-                cnt += total;
             }
         }
-        if (pass == 0) {
-            if (lane == 0) wave_cnt[wid] = cnt;
-            __syncthreads();
-            const int c0 = wave_cnt[0], c1 = wave_cnt[1], c2 = wave_cnt[2], c3 = wave_cnt[3];
-            const int total = c0 + c1 + c2 + c3;
-            if (tid == 0) {
-                int off = 0;
-                if (total > 0) off = (int)atomicAdd(&fs[0], (unsigned)total);
-                pool_off = off;
-                const int nb4 = (nbands + 3) / 4 * 4;
-                fs[4 + band] = (unsigned)off;
-                fs[4 + nb4 + band] = (unsigned)total;
-            }
-            __syncthreads();
-            base = pool_off + ((wid == 0) ? 0 : (wid == 1) ? c0 : (wid == 2) ? c0 + c1 : c0 + c1 + c2);
-            if (total == 0) break;
-        }
+        if (lane == 0 && seg < nseg) rowcnt[seg] = (unsigned)total;
     }
 }
 
-// One workgroup per (band, frame): finds the band's place in the frame's output by summing the
-// counts of the bands before it, then converts and copies its keys.
-__global__ __launch_bounds__(FAST_WG) void fast_gather_kernel(int w, int R, int nbands, int cap,
-                                                              const unsigned* __restrict__ scratch,
-                                                              slam_keypoint* __restrict__ out,
-                                                              int* __restrict__ counts) {
-    __shared__ int part[4];
-    const int band = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
-    const unsigned* fs = scratch + (size_t)frame * fast_frame_words(nbands, cap);
-    const int nb4 = (nbands + 3) / 4 * 4;
-    const unsigned* band_off = fs + 4;
-    const unsigned* band_cnt = fs + 4 + nb4;
-    const unsigned* pool = fs + 4 + 2 * nb4;
-    slam_keypoint* o = out + (size_t)frame * cap;
-    unsigned mine = 0;
-    for (int b = tid; b < band; b += FAST_WG) mine += band_cnt[b];
-    const unsigned tot = wave_scan_incl(mine);
-    if ((tid & 63) == 63) part[tid >> 6] = (int)tot;
+// One workgroup per frame: exclusive prefix sums of the (row, tile) counts in row-major order.
+__global__ __launch_bounds__(FAST_WG) void fast_scan_kernel(int h, int ntx, unsigned* __restrict__ scratch, int* __restrict__ counts) {
+    __shared__ unsigned part[4];
+    __shared__ unsigned carry;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    unsigned* fs = scratch + (size_t)frame * fast_frame_words(h, ntx);
+    const unsigned* rowcnt = fs;
+    unsigned* rowoff = fs + fast_tab_words(h, ntx);
+    const int n = h * ntx;
+    if (tid == 0) carry = 0u;
     __syncthreads();
-    const int base = part[0] + part[1] + part[2] + part[3];
-    const int cnt = (int)band_cnt[band], off = (int)band_off[band];
-    for (int i = tid; i < cnt; i += FAST_WG) {
-        const int dst = base + i;
-        if (dst < cap && off + i < cap) {
-            const unsigned key = pool[off + i];
-            const unsigned lin = key >> 8;
-            const int ry = (int)(lin / (unsigned)w), x = (int)(lin - (unsigned)ry * (unsigned)w);
-            slam_keypoint kp;
-            kp.x = (float)x; kp.y = (float)(band * R + ry); kp.response = (float)(key & 0xffu);
-            o[dst] = kp;
+    for (int base = 0; base < n; base += FAST_WG * 4) {
+        const int i0 = base + tid * 4;
+        unsigned c[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[q] = (i0 + q < n) ? rowcnt[i0 + q] : 0u;
+        const unsigned mine = c[0] + c[1] + c[2] + c[3];
+        const unsigned incl = wave_scan_incl(mine);
+        if ((tid & 63) == 63) part[tid >> 6] = incl;
+        __syncthreads();
+        unsigned off = carry + incl - mine;
+        for (int k = 0; k < (tid >> 6); k++) off += part[k];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (i0 + q < n) rowoff[i0 + q] = off;
+            off += c[q];
+        }
+        __syncthreads();
+        if (tid == 0) carry += part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+    if (tid == 0) counts[frame] = (int)carry;
+}
+
+// One wavefront per tile: lane r looks up row r's segment, then the non-empty segments are copied to
+// their places one after the other by all lanes.
+__global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx, int cap, const unsigned* __restrict__ scratch,
+                                                          slam_keypoint* __restrict__ out) {
+    const int tx = blockIdx.x, ty = blockIdx.y, frame = blockIdx.z;
+    const int lane = threadIdx.x;
+    const unsigned* fs = scratch + (size_t)frame * fast_frame_words(h, ntx);
+    const unsigned* rowcnt = fs;
+    const unsigned* rowoff = fs + fast_tab_words(h, ntx);
+    const unsigned short* keys = reinterpret_cast<const unsigned short*>(fs + 2 * fast_tab_words(h, ntx));
+    slam_keypoint* o = out + (size_t)frame * cap;
+    const int y_l = ty * FAST_TH + lane;
+    int n_l = 0, off_l = 0;
+    if (lane < FAST_TH && y_l < h) { n_l = (int)rowcnt[y_l * ntx + tx]; off_l = (int)rowoff[y_l * ntx + tx]; }
+    unsigned long long todo = __ballot(n_l > 0);
+    while (todo) {
+        const int r = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int n = __builtin_amdgcn_readlane(n_l, r);
+        const long long off = (long long)(unsigned)__builtin_amdgcn_readlane(off_l, r);
+        const int y = ty * FAST_TH + r;
+        const unsigned short* kseg = keys + (size_t)(y * ntx + tx) * FAST_TW;
+        for (int i = lane; i < n; i += 64) {
+            if (off + i < cap) {
+                const unsigned key = kseg[i];
+                slam_keypoint kp;
+                kp.x = (float)(tx * FAST_TW + (int)(key >> 8)); kp.y = (float)y; kp.response = (float)(key & 0xffu);
+                o[off + i] = kp;
+            }
         }
     }
-    if (band == nbands - 1 && tid == 0) counts[frame] = base + cnt;
 }
 
 }  // namespace
@@ -457,7 +404,7 @@ extern "C" size_t slam_hip_fast_scratch_bytes(int w, int h, int nframes, int cap
     FastPlan p;
     if (w < 1 || h < 1 || nframes < 1 || cap_per_frame < 1) return 0;
     if (!fast_plan(w, h, p)) return 0;
-    return fast_frame_words(p.nbands, cap_per_frame) * 4 * (size_t)nframes;
+    return fast_frame_words(h, p.ntx) * 4 * (size_t)nframes;     // independent of the output capacity
 }
 
 extern "C" int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, int w, int h, size_t pitch,
@@ -471,20 +418,23 @@ extern "C" int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, in
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: bad arguments");
     FastPlan p;
     if (!fast_plan(w, h, p))
-        return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: image too wide (%d) for the band kernel", w);
-    const size_t need = fast_frame_words(p.nbands, cap_per_frame) * 4 * (size_t)nframes;
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: unsupported image size %d x %d", w, h);
+    if (nframes > 65535 || p.nty > 65535)
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: at most 65535 frames and tile rows per call");
+    const size_t need = fast_frame_words(h, p.ntx) * 4 * (size_t)nframes;
     if (scratch_bytes < need || ((uintptr_t)d_scratch & 15))
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: scratch too small or misaligned (%zu < %zu)", scratch_bytes, need);
     threshold = std::min(std::max(threshold, 0), 255);          // cv::FAST clamps the threshold
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    // zero the pool counters (first word of every frame record); the records are 16-byte multiples
-    SLAM_HIP_CHECK(ctx, hipMemset2DAsync(d_scratch, fast_frame_words(p.nbands, cap_per_frame) * 4, 0, 16, (size_t)nframes, ctx->stream));
-    hipLaunchKernelGGL(fast_band_kernel, dim3(p.nbands, nframes), dim3(FAST_WG), p.lds_bytes, ctx->stream,
+    // every word of the tables that is read is written by the kernel before it: nothing to clear
+    hipLaunchKernelGGL(fast_tile_kernel, dim3(p.ntx, p.nty, nframes), dim3(FAST_WG), 0, ctx->stream,
                        d_frames, w, h, (long long)pitch, (long long)frame_stride, threshold, nonmax ? 1 : 0,
-                       p.R, p.spitch, p.nbands, cap_per_frame, (unsigned*)d_scratch);
+                       p.ntx, (unsigned*)d_scratch);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(fast_gather_kernel, dim3(p.nbands, nframes), dim3(FAST_WG), 0, ctx->stream, w, p.R, p.nbands,
-                       cap_per_frame, (const unsigned*)d_scratch, d_out, d_counts);
+    hipLaunchKernelGGL(fast_scan_kernel, dim3(nframes), dim3(FAST_WG), 0, ctx->stream, h, p.ntx, (unsigned*)d_scratch, d_counts);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(fast_scatter_kernel, dim3(p.ntx, p.nty, nframes), dim3(64), 0, ctx->stream, w, h, p.ntx,
+                       cap_per_frame, (const unsigned*)d_scratch, d_out);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }

@@ -277,6 +277,7 @@ def test_fast_capacity_is_reported(ctx, oracle):
     assert len(ref) > 50
     got, counts, rc = api.fast(ctx, frame, 10, True, cap=32)
     assert rc == api.capi.ECAP and counts[0] == len(ref) and len(got[0]) == 32
+    assert np.array_equal(got[0], ref[:32])          # a truncated list is the exact row-major prefix
 
 
 def test_get_sorted_keypoints_matches_oracle(ctx, oracle):
