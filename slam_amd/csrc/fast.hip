@@ -365,10 +365,12 @@ __global__ __launch_bounds__(FAST_WG) void fast_scan_kernel(int h, int ntx, unsi
     if (tid == 0) counts[frame] = (int)carry;
 }
 
-// One wavefront per tile: lane r looks up row r's segment, then the non-empty segments are copied to
-// their places one after the other by all lanes.
+// One wavefront per tile: lane r looks up row r's segment; the tile's keys are then numbered across its
+// rows and dealt to the lanes 64 at a time (a binary search over the rows' running totals finds the
+// segment of key number i), so the lanes stay busy however few keys a single row holds.
 __global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx, int cap, const unsigned* __restrict__ scratch,
                                                           slam_keypoint* __restrict__ out) {
+    __shared__ int start_s[32], off_s[32];
     const int tx = blockIdx.x, ty = blockIdx.y, frame = blockIdx.z;
     const int lane = threadIdx.x;
     const unsigned* fs = scratch + (size_t)frame * fast_frame_words(h, ntx);
@@ -379,21 +381,24 @@ __global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx,
     const int y_l = ty * FAST_TH + lane;
     int n_l = 0, off_l = 0;
     if (lane < FAST_TH && y_l < h) { n_l = (int)rowcnt[y_l * ntx + tx]; off_l = (int)rowoff[y_l * ntx + tx]; }
-    unsigned long long todo = __ballot(n_l > 0);
-    while (todo) {
-        const int r = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        const int n = __builtin_amdgcn_readlane(n_l, r);
-        const long long off = (long long)(unsigned)__builtin_amdgcn_readlane(off_l, r);
-        const int y = ty * FAST_TH + r;
-        const unsigned short* kseg = keys + (size_t)(y * ntx + tx) * FAST_TW;
-        for (int i = lane; i < n; i += 64) {
-            if (off + i < cap) {
-                const unsigned key = kseg[i];
-                slam_keypoint kp;
-                kp.x = (float)(tx * FAST_TW + (int)(key >> 8)); kp.y = (float)y; kp.response = (float)(key & 0xffu);
-                o[off + i] = kp;
-            }
+    const int incl = (int)wave_scan_incl((unsigned)n_l);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;
+    if (lane < 32) { start_s[lane] = incl - n_l; off_s[lane] = off_l; }   // rows 30 and 31 start at `total`
+    __syncthreads();
+    for (int i = lane; i < total; i += 64) {
+        int r = 0;                                   // last row whose first key number is <= i
+#pragma unroll
+        for (int step = 16; step >= 1; step >>= 1)
+            if (start_s[r + step] <= i) r += step;
+        const int k = i - start_s[r];
+        const long long dst = (long long)(unsigned)off_s[r] + k;
+        if (dst < cap) {
+            const int y = ty * FAST_TH + r;
+            const unsigned key = keys[(size_t)(y * ntx + tx) * FAST_TW + k];
+            slam_keypoint kp;
+            kp.x = (float)(tx * FAST_TW + (int)(key >> 8)); kp.y = (float)y; kp.response = (float)(key & 0xffu);
+            o[dst] = kp;
         }
     }
 }

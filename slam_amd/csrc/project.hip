@@ -54,7 +54,8 @@ __global__ __launch_bounds__(WARP_WG) void warp_kernel(const uint8_t* __restrict
     uint8_t* P = out + job.proj_off;
     uint8_t* K = job.mask_off >= 0 ? out + job.mask_off : nullptr;
     const int total = (int)npix;
-    for (int i = blockIdx.y * WARP_WG + threadIdx.x; i < total; i += gridDim.y * WARP_WG) {
+    const int nthr = blockDim.x;                  // 64 for batches of small outputs, WARP_WG otherwise
+    for (int i = blockIdx.y * nthr + threadIdx.x; i < total; i += gridDim.y * nthr) {
         const int y = i / ow, x = i - y * ow;
         const int xb = (x / bw0) * bw0, x1 = x - xb;
         const double X0 = M0 * xb + M1 * y + M2;
@@ -63,8 +64,12 @@ __global__ __launch_bounds__(WARP_WG) void warp_kernel(const uint8_t* __restrict
         const double Wd = W0 + M6 * x1;
         const double nx = X0 + M0 * x1, ny = Y0 + M3 * x1;
         const double lo = -2147483648.0, hi = 2147483647.0;
+        // One division serves both maps: 32/Wd == 32 * (1/Wd) bit for bit, a scaling by a power of two being
+        // exact (|Wd| is far from the overflow and underflow ranges: the matrix entries are floats below 1e30
+        // and the coordinates are below 4096).
+        const double inv = Wd != 0.0 ? 1.0 / Wd : 0.0;
         {
-            const double W = Wd != 0.0 ? 32.0 / Wd : 0.0;
+            const double W = 32.0 * inv;
             double fX = nx * W, fY = ny * W;
             fX = fX < hi ? fX : hi; fX = fX > lo ? fX : lo;       // std::max(INT_MIN, std::min(INT_MAX, v))
             fY = fY < hi ? fY : hi; fY = fY > lo ? fY : lo;
@@ -81,8 +86,7 @@ __global__ __launch_bounds__(WARP_WG) void warp_kernel(const uint8_t* __restrict
             P[i] = (uint8_t)(((top * (32 - ay) + bot * ay) * 32 + (1 << 14)) >> 15);
         }
         if (K) {
-            const double W = Wd != 0.0 ? 1.0 / Wd : 0.0;
-            double fX = nx * W, fY = ny * W;
+            double fX = nx * inv, fY = ny * inv;
             fX = fX < hi ? fX : hi; fX = fX > lo ? fX : lo;
             fY = fY < hi ? fY : hi; fY = fY > lo ? fY : lo;
             const int sx = sat_s16(__double2int_rn(fX)), sy = sat_s16(__double2int_rn(fY));
@@ -167,10 +171,13 @@ extern "C" int slam_hip_warp_batch_d(slam_ctx* ctx, const uint8_t* d_desc, size_
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "warp_batch: null table or negative count");
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    // slices of 16 pixels per lane; a job larger than the hint is still completed (grid-stride loop)
-    int slices = max_out_pixels > 0 ? (max_out_pixels + WARP_WG * 16 - 1) / (WARP_WG * 16) : 1;
+    // slices of 16 pixels per lane; a job larger than the hint is still completed (grid-stride loop).
+    // Outputs known to be small get one wavefront each: a 21x21 projection fills 7 passes of 64 lanes
+    // but only 1.7 passes of 256.
+    const int nthr = (max_out_pixels > 0 && max_out_pixels <= 1024) ? 64 : WARP_WG;
+    int slices = max_out_pixels > 0 ? (max_out_pixels + nthr * 16 - 1) / (nthr * 16) : 1;
     slices = std::min(std::max(slices, 1), 64);
-    hipLaunchKernelGGL(warp_kernel, dim3(njobs, slices), dim3(WARP_WG), 0, ctx->stream, d_desc,
+    hipLaunchKernelGGL(warp_kernel, dim3(njobs, slices), dim3(nthr), 0, ctx->stream, d_desc,
                        (unsigned long long)desc_bytes, d_jobs, njobs, d_out, (unsigned long long)out_bytes, d_status);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
