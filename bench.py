@@ -39,7 +39,8 @@ TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profile
 
 TRACK_JOB_DT = np.dtype([("frame", "<i4"), ("projw", "<i4"), ("projh", "<i4"), ("_pad", "<i4"),
                          ("proj_off", "<i8"), ("mask_off", "<i8"), ("px", "<f4"), ("py", "<f4"),
-                         ("threshold", "<f4"), ("stride", "<i4")])
+                         ("threshold", "<f4"), ("stride", "<i4"),
+                         ("amask_off", "<i8"), ("ax", "<i4"), ("ay", "<i4"), ("aw", "<i4"), ("ah", "<i4")])
 TRACK_RES_DT = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<f4"), ("dx", "<f4"), ("dy", "<f4"),
                          ("levels_run", "<i4"), ("status", "<i4")])
 

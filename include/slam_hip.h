@@ -150,11 +150,21 @@ int slam_hip_match_feature_in_area(slam_ctx* ctx,
 typedef struct slam_track_job {
     int32_t frame;
     int32_t projw, projh;           /* size of proj; 0 = empty projection (feature.cpp:112-115) */
+    int32_t flags;                  /* 0 = the reference's walk; SLAM_HIP_TRACK_COARSE_AREA: see below */
     int64_t proj_off, mask_off;     /* proj and proj_mask in the blob, pitch projw */
     float   px, py;                 /* state.project(p3d) */
     float   threshold;
     int32_t stride;
+    /* With SLAM_HIP_TRACK_COARSE_AREA (not in the reference, whose coarsest window is the fixed square of
+     * feature.cpp:134,144-146): the coarsest level is searched in this rectangle (that level's pixels)
+     * under this area mask (pitch aw, tested for non-zero; -1: no mask) - e.g. the rasterised uncertainty
+     * ellipse of the prediction - as matchFeatureInArea(level, totrack, &mask, areaRect, &areaMask, stride);
+     * the finer levels follow the reference's rule.  Ignored (may be left zero) without the flag. */
+    int64_t amask_off;
+    int32_t ax, ay, aw, ah;
 } slam_track_job;
+
+#define SLAM_HIP_TRACK_COARSE_AREA 1
 
 typedef struct slam_track_result {
     int32_t x, y;        /* returned Point2i; (-1,-1) for an empty projection */

@@ -77,6 +77,8 @@ def lib():
                                C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(TrackOut)]
         L.so_track.restype = C.c_int
+        L.so_track_ex.argtypes = L.so_track.argtypes[:-1] + [C.c_void_p, C.c_void_p, C.POINTER(TrackOut)]
+        L.so_track_ex.restype = C.c_int
         L.so_fast_score_map.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p]
         L.so_fast_score_map.restype = None
         L.so_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int,
@@ -182,8 +184,9 @@ def match(im, patch, patch_mask, area, area_mask, stride, exact=False, want_scor
     return r
 
 
-def track(levels, subs, proj, proj_mask, px, py, threshold, stride):
-    """Feature::track after project(): levels = pyramid images, proj/proj_mask full-res template."""
+def track(levels, subs, proj, proj_mask, px, py, threshold, stride, coarse_area=None, coarse_mask=None):
+    """Feature::track after project(): levels = pyramid images, proj/proj_mask full-res template.
+    coarse_area=(x, y, w, h) [+ coarse_mask]: the build's extension, see so_track_ex."""
     levels = [_u8(l) for l in levels]
     n = len(levels)
     ptrs = (C.c_void_p * n)(*[l.ctypes.data for l in levels])
@@ -194,9 +197,13 @@ def track(levels, subs, proj, proj_mask, px, py, threshold, stride):
     pm = _u8(proj_mask)
     assert pm.shape == proj.shape
     out = TrackOut()
-    rc = lib().so_track(ptrs, lw, lh, fs, n, proj.ctypes.data, pm.ctypes.data,
-                        proj.shape[1], proj.shape[0], C.c_float(px), C.c_float(py),
-                        C.c_float(threshold), stride, C.byref(out))
+    ca = (C.c_int * 4)(*coarse_area) if coarse_area is not None else None
+    cm = _u8(coarse_mask) if coarse_mask is not None else None
+    if cm is not None:
+        assert cm.shape == (coarse_area[3], coarse_area[2])
+    rc = lib().so_track_ex(ptrs, lw, lh, fs, n, proj.ctypes.data, pm.ctypes.data,
+                           proj.shape[1], proj.shape[0], C.c_float(px), C.c_float(py),
+                           C.c_float(threshold), stride, ca, cm.ctypes.data if cm is not None else None, C.byref(out))
     if rc != 0:
         raise ValueError("so_track: bad arguments")
     return dict(x=out.x, y=out.y, response=out.response, dx=out.dx, dy=out.dy,

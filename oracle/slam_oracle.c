@@ -323,6 +323,16 @@ int so_match_feature_in_area(const uint8_t* im, int w, int h, ptrdiff_t ipitch,
 int so_track(uint8_t* const* levels, const int* lw, const int* lh, const float* subs, int nlev,
              const uint8_t* proj, const uint8_t* proj_mask, int projw, int projh,
              float px, float py, float threshold, int stride, so_track_out* out) {
+    return so_track_ex(levels, lw, lh, subs, nlev, proj, proj_mask, projw, projh, px, py, threshold, stride, NULL, NULL, out);
+}
+
+/* The same walk; with coarse_area (x, y, w, h in the coarsest level's pixels) that level is searched
+ * in the given window under coarse_mask (pitch w, or NULL) instead of the square of feature.cpp:134,
+ * 144-146 - an extension of the build (elliptical uncertainty windows), not reference behaviour. */
+int so_track_ex(uint8_t* const* levels, const int* lw, const int* lh, const float* subs, int nlev,
+                const uint8_t* proj, const uint8_t* proj_mask, int projw, int projh,
+                float px, float py, float threshold, int stride,
+                const int* coarse_area, const uint8_t* coarse_mask, so_track_out* out) {
     memset(out, 0, sizeof(*out));
     if (nlev < 1 || stride < 1) return -1;
     if (projw <= 0 || projh <= 0) {                 /* feature.cpp:112-115 */
@@ -361,12 +371,17 @@ int so_track(uint8_t* const* levels, const int* lw, const int* lh, const float* 
             if (iSub == 0) searchRad *= stride;     /* feature.cpp:137-138 */
         }
         /* feature.cpp:144-146: round() on float expressions */
-        const int rx = (int)round((double)(tx / sub - searchRad));
-        const int ry = (int)round((double)(ty / sub - searchRad));
-        const int rs = (int)round((double)(2 * searchRad + 1));
+        int rx = (int)round((double)(tx / sub - searchRad));
+        int ry = (int)round((double)(ty / sub - searchRad));
+        int rw = (int)round((double)(2 * searchRad + 1)), rh = rw;
+        const uint8_t* am = NULL;
+        if (coarse_area && iSub == nlev - 1) {
+            rx = coarse_area[0]; ry = coarse_area[1]; rw = coarse_area[2]; rh = coarse_area[3];
+            am = coarse_mask;
+        }
         so_match_out m;
         so_match_feature_in_area(levels[iSub], lw[iSub], lh[iSub], lw[iSub], totrack, tw, th, tw,
-                                 totrack_mask, tw, rx, ry, rs, rs, NULL, 0,
+                                 totrack_mask, tw, rx, ry, rw, rh, am, rw,
                                  (iSub == 0) ? 1 : stride, 0, NULL, &m);   /* feature.cpp:147-149 */
         response = m.response;
         tx = (float)m.x; ty = (float)m.y;

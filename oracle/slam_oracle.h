@@ -84,6 +84,14 @@ int so_track(uint8_t* const* levels, const int* lw, const int* lh, const float* 
              const uint8_t* proj, const uint8_t* proj_mask, int projw, int projh,
              float px, float py, float threshold, int stride, so_track_out* out);
 
+/* so_track with the coarsest level searched in coarse_area = {x, y, w, h} (that level's pixels) under
+ * coarse_mask (pitch w, tested for non-zero, or NULL) instead of the reference's fixed square.  Not in
+ * the reference: the build's elliptical-uncertainty windows.  coarse_area == NULL is so_track. */
+int so_track_ex(uint8_t* const* levels, const int* lw, const int* lh, const float* subs, int nlev,
+                const uint8_t* proj, const uint8_t* proj_mask, int projw, int projh,
+                float px, float py, float threshold, int stride,
+                const int* coarse_area, const uint8_t* coarse_mask, so_track_out* out);
+
 /* lineFeature.cpp:86-96: the area mask of LineFeature::track, zero-filled w x h with one filled
  * cv::circle of value 255 per (x, y, radius) triple.  Returns 0 / -1. */
 int so_disc_mask(int w, int h, const int* circles, int ncircles, uint8_t* mask);

@@ -179,6 +179,87 @@ def main():
                                     "positions/s": cells * nfr * nline / (ms * 1e-3),
                                     "u8_mac/s": (60 * 40 * 40 * 40 + 25 * 81 * 81) * 2.0 * nfr * nline / (ms * 1e-3)}
     pyr.close()
+    del d_fr
+
+    # --- C1: 320x240, 16 features, 11x11 templates, one level, 41x41 windows, stride 1, all four mask modes
+    # (matchFeatureInArea jobs), 1024 frames
+    w, h, nfr, nfeat, ts = 320, 240, 1024, 16, 11
+    f1 = synth.frame(w, h, synth.SEED_BASE + 1)
+    d_fr = torch.from_numpy(f1).to(dev).unsqueeze(0).repeat(nfr, 1, 1).contiguous()
+    pyr = api.ImagePyramid(ctx, None, [1.0], device_ptr=d_fr.data_ptr(), pitch=w, frame_stride=w * h, shape=(nfr, h, w))
+    pts = synth.feature_grid(w, h, nfeat, 30, rng)
+    mj = (capi.MatchJob * (nfr * nfeat))()
+    parts, off = [], 0
+    per_feat = []
+    for k, (cx, cy) in enumerate(pts):
+        patch = synth.cut_template(f1, cx, cy, ts, ts)
+        pm = rng.integers(0, 2, (ts, ts), dtype=np.uint8)
+        am = synth.ellipse_mask(41, 41, 18.0, 9.0, 0.3 * k)
+        o = [off, off + patch.size, off + 2 * patch.size]
+        parts += [patch.reshape(-1), pm.reshape(-1), am.reshape(-1)]
+        off += 2 * patch.size + am.size
+        per_feat.append(o)
+    cells = 0
+    for f in range(nfr):
+        for k, (cx, cy) in enumerate(pts):
+            j = mj[f * nfeat + k]
+            mode = (f + k) & 3
+            j.frame, j.level, j.pw, j.ph = f, 0, ts, ts
+            j.patch_off = per_feat[k][0]
+            j.pmask_off = per_feat[k][1] if mode & 1 else -1
+            j.ax, j.ay, j.aw, j.ah = cx - 20, cy - 20, 41, 41
+            j.amask_off = per_feat[k][2] if mode & 2 else -1
+            j.stride, j.use_exact_area_mask, j.score_off = 1, 0, -1
+            cells += 41 * 41
+    d_blob = torch.from_numpy(np.concatenate(parts)).to(dev)
+    d_mj = torch.from_numpy(np.frombuffer(bytes(mj), np.uint8).copy()).to(dev)
+    d_res = torch.zeros(nfr * nfeat * 24, dtype=torch.uint8, device=dev)
+    ms = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_match_batch_d(ctx.handle, pyr.handle, P(d_mj), nfr * nfeat, P(d_blob), off,
+                                                                                None, 0, P(d_res))))
+    alg = nfr * nfeat * (51 * 51 + ts * ts + 20)
+    out["c1_match_16384x11x11_41x41"] = {"ms": ms, "jobs": nfr * nfeat, "positions/s": cells / (ms * 1e-3), "alg_bytes": alg,
+                                         "GB/s": alg / (ms * 1e-3) / 1e9, "frac_hbm": alg / (ms * 1e-3) / 8e12,
+                                         "u8_mac/s": cells * 2.0 * ts * ts / (ms * 1e-3)}
+    pyr.close()
+    del d_fr, d_blob, d_mj, d_res
+
+    # --- C3: 1280x720, 256 features, 31x31 masked templates, pyramid {1,2,4,8}, ellipse windows on the coarsest
+    # level (track walk with SLAM_HIP_TRACK_COARSE_AREA), 256 frames
+    w, h, nfr, nfeat, ts, subs = 1280, 720, 256, 256, 31, [1.0, 2.0, 4.0, 8.0]
+    shift = (5, -4)
+    f0, f1 = synth.frame(w, h, synth.SEED_BASE + 33), synth.frame(w, h, synth.SEED_BASE + 33, shift)
+    d_fr = torch.from_numpy(f1).to(dev).unsqueeze(0).repeat(nfr, 1, 1).contiguous()
+    pyr = api.ImagePyramid(ctx, None, subs, device_ptr=d_fr.data_ptr(), pitch=w, frame_stride=w * h, shape=(nfr, h, w))
+    pts = synth.feature_grid(w, h, nfeat, ts + 30, rng)
+    tj = (capi.TrackJob * (nfr * nfeat))()
+    parts, off, feats = [], 0, []
+    for (cx, cy) in pts:
+        proj = synth.cut_template(f0, cx, cy, ts, ts)
+        mask = np.ones_like(proj); mask[0, :5] = 0; mask[-1, -5:] = 0
+        a, b, th = float(rng.uniform(24, 96)) / 8, float(rng.uniform(12, 48)) / 8, float(rng.uniform(0, np.pi))
+        ew = 2 * int(np.ceil(max(a, b))) + 1
+        am = synth.ellipse_mask(ew, ew, a, b, th)
+        px, py = cx - shift[0] + float(rng.integers(-10, 11)) + 0.4, cy - shift[1] + float(rng.integers(-6, 7)) - 0.3
+        feats.append((off, off + proj.size, off + 2 * proj.size, ew, px, py, int(am.sum())))
+        parts += [proj.reshape(-1), mask.reshape(-1), am.reshape(-1)]
+        off += 2 * proj.size + am.size
+    for f in range(nfr):
+        for k, (po, mo, ao, ew, px, py, _) in enumerate(feats):
+            t = tj[f * nfeat + k]
+            t.frame, t.projw, t.projh, t.flags = f, ts, ts, capi.TRACK_COARSE_AREA
+            t.proj_off, t.mask_off, t.amask_off = po, mo, ao
+            t.px, t.py, t.threshold, t.stride = px, py, 0.9, 3
+            t.ax, t.ay, t.aw, t.ah = int(round(px / 8)) - ew // 2, int(round(py / 8)) - ew // 2, ew, ew
+    d_blob = torch.from_numpy(np.concatenate(parts)).to(dev)
+    d_tj = torch.from_numpy(np.frombuffer(bytes(tj), np.uint8).copy()).to(dev)
+    d_res = torch.zeros(nfr * nfeat * 28, dtype=torch.uint8, device=dev)
+    ms = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_tj), nfr * nfeat, P(d_blob), off, P(d_res))))
+    res = d_res.cpu().numpy().view(np.int32).reshape(-1, 7)
+    ms_p = timed(stream, lambda: pyr.rebuild_d(d_fr.data_ptr(), w, w * h))
+    out["c3_track_65536x31x31_ellipse"] = {"ms_track": ms, "ms_pyramid": ms_p, "jobs": nfr * nfeat, "frames": nfr,
+                                           "all_levels": float((res[:, 5] == 4).mean()), "frames/s": nfr / ((ms + ms_p) * 1e-3),
+                                           "features/s": nfr * nfeat / ((ms + ms_p) * 1e-3)}
+    pyr.close()
     print(json.dumps(out, indent=1))
     ctx.close()
 

@@ -221,7 +221,9 @@ def match_batch(ctx, pyr, jobs):
 
 
 def track_batch(ctx, pyr, jobs):
-    """jobs: list of dicts(frame, proj, proj_mask, px, py, threshold, stride) -> Feature::track results."""
+    """jobs: list of dicts(frame, proj, proj_mask, px, py, threshold, stride) -> Feature::track results.
+    Optional per job: coarse_area=(x, y, w, h) and coarse_mask (or None): the coarsest level is searched in that
+    window under that area mask instead of the reference's fixed square (SLAM_HIP_TRACK_COARSE_AREA)."""
     n = len(jobs)
     blob = Blob()
     arr = (TrackJob * max(n, 1))()
@@ -242,6 +244,13 @@ def track_batch(ctx, pyr, jobs):
         a.px, a.py = float(j["px"]), float(j["py"])
         a.threshold = float(j["threshold"])
         a.stride = int(j["stride"])
+        if j.get("coarse_area") is not None:
+            a.flags = capi.TRACK_COARSE_AREA
+            a.ax, a.ay, a.aw, a.ah = j["coarse_area"]
+            cm = j.get("coarse_mask")
+            if cm is not None and _u8(cm).shape != (a.ah, a.aw):
+                raise ValueError("coarse mask shape")
+            a.amask_off = blob.add(cm)
     b = blob.bytes()
     res = (TrackResult * max(n, 1))()
     check(ctx.handle, lib().slam_hip_track_batch(ctx.handle, pyr.handle, arr, n, b.ctypes.data, b.size, res))

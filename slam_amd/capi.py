@@ -39,9 +39,13 @@ class MatchResult(C.Structure):
 
 
 class TrackJob(C.Structure):
-    _fields_ = [("frame", C.c_int32), ("projw", C.c_int32), ("projh", C.c_int32),
+    _fields_ = [("frame", C.c_int32), ("projw", C.c_int32), ("projh", C.c_int32), ("flags", C.c_int32),
                 ("proj_off", C.c_int64), ("mask_off", C.c_int64),
-                ("px", C.c_float), ("py", C.c_float), ("threshold", C.c_float), ("stride", C.c_int32)]
+                ("px", C.c_float), ("py", C.c_float), ("threshold", C.c_float), ("stride", C.c_int32),
+                ("amask_off", C.c_int64), ("ax", C.c_int32), ("ay", C.c_int32), ("aw", C.c_int32), ("ah", C.c_int32)]
+
+
+TRACK_COARSE_AREA = 1
 
 
 class TrackResult(C.Structure):

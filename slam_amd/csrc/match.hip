@@ -231,10 +231,15 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         return;
     }
     const long long pbytes = (long long)job.projw * job.projh;
-    const bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.projw <= SLAM_MAX_TMPL && job.projh <= SLAM_MAX_TMPL &&
-                    job.stride >= 1 && job.stride <= 1024 &&
-                    span_ok(job.proj_off, pbytes, blob_bytes) && span_ok(job.mask_off, pbytes, blob_bytes) &&
-                    fabsf(job.px) < 1e7f && fabsf(job.py) < 1e7f && job.threshold == job.threshold;
+    bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.projw <= SLAM_MAX_TMPL && job.projh <= SLAM_MAX_TMPL &&
+              job.stride >= 1 && job.stride <= 1024 &&
+              span_ok(job.proj_off, pbytes, blob_bytes) && span_ok(job.mask_off, pbytes, blob_bytes) &&
+              fabsf(job.px) < 1e7f && fabsf(job.py) < 1e7f && job.threshold == job.threshold;
+    const bool coarse_area = (job.flags & SLAM_HIP_TRACK_COARSE_AREA) != 0;
+    if (coarse_area)
+        ok = ok && job.aw >= 1 && job.ah >= 1 && job.aw <= (1 << 12) && job.ah <= (1 << 12) &&
+             job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28) &&
+             (job.amask_off == -1 || span_ok(job.amask_off, (long long)job.aw * job.ah, blob_bytes));
     if (!ok) {
         if (tid == 0) { slam_track_result r = {-1, -1, -1.f, 0.f, 0.f, 0, SLAM_HIP_EINVAL}; out[j] = r; }
         return;
@@ -292,10 +297,16 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
         t.scale_x = lane_f64(scx_l, i); t.scale_y = lane_f64(scy_l, i);
         // feature.cpp:144-146
-        const int rx = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(tx, sub), searchRad)));
-        const int ry = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(ty, sub), searchRad)));
-        const Geo g = make_geo(ld + (long long)job.frame * ls, lw, lh, lp, t.tw, t.th, rx, ry, rs, rs,
-                               nullptr, (i == 0) ? 1 : job.stride, true, false);   // feature.cpp:147-149
+        int rx = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(tx, sub), searchRad)));
+        int ry = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(ty, sub), searchRad)));
+        int rw = rs, rh = rs;
+        const uint8_t* am = nullptr;
+        if (coarse_area && i == pyr.nlev - 1) {                  // caller's window and area mask on the coarsest level
+            rx = job.ax; ry = job.ay; rw = job.aw; rh = job.ah;
+            if (job.amask_off != -1) am = blob + job.amask_off;
+        }
+        const Geo g = make_geo(ld + (long long)job.frame * ls, lw, lh, lp, t.tw, t.th, rx, ry, rw, rh,
+                               am, (i == 0) ? 1 : job.stride, true, false);   // feature.cpp:147-149
         int mx = 0, my = 0;
         sdx = 0.f; sdy = 0.f;
         levels_run++;

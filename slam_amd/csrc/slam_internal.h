@@ -90,7 +90,7 @@ int slam_pyr_detect_box(const std::vector<int32_t>& xofs, const std::vector<uint
                         int sw, int sh, int dw, int dh);
 
 static_assert(sizeof(slam_match_job) == 72 && sizeof(slam_match_result) == 24, "ABI struct layout");
-static_assert(sizeof(slam_track_job) == 48 && sizeof(slam_track_result) == 28, "ABI struct layout");
+static_assert(sizeof(slam_track_job) == 72 && sizeof(slam_track_result) == 28, "ABI struct layout");
 static_assert(sizeof(slam_keypoint) == 12, "ABI struct layout");
 static_assert(sizeof(slam_desc_job) == 32 && sizeof(slam_desc_result) == 20, "ABI struct layout");
 static_assert(sizeof(slam_warp_job) == 80, "ABI struct layout");

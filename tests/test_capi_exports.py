@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     from slam_amd import capi
     assert C.sizeof(capi.MatchJob) == 72
     assert C.sizeof(capi.MatchResult) == 24
-    assert C.sizeof(capi.TrackJob) == 48
+    assert C.sizeof(capi.TrackJob) == 72
     assert C.sizeof(capi.TrackResult) == 28
     assert C.sizeof(capi.KeyPoint) == 12
     assert C.sizeof(capi.DescJob) == 32

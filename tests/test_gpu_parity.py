@@ -434,3 +434,55 @@ def test_c3_ellipse_windows_all_levels(ctx, oracle):
             assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
     finally:
         pyr.close()
+
+
+def _c3_jobs(rng, w, h, subs, nfeat, tsize, frame0, shift):
+    """C3: every feature carries an uncertainty ellipse (full-resolution semi-axes a in [24,96], b in [12,48], any
+    angle); its bounding box on the coarsest level, centred on the prediction, is the coarse search window and the
+    rasterised ellipse its area mask."""
+    top = float(subs[-1])
+    jobs = []
+    for (cx, cy) in synth.feature_grid(w, h, nfeat, tsize + 30, rng):
+        proj = synth.cut_template(frame0, cx, cy, tsize, tsize)
+        mask = np.ones_like(proj)
+        k = int(rng.integers(0, tsize // 3 + 1))
+        for r in range(k):
+            mask[r, :k - r] = 0
+            mask[tsize - 1 - r, tsize - (k - r):] = 0
+        px = cx - shift[0] + float(rng.integers(-10, 11)) + 0.4
+        py = cy - shift[1] + float(rng.integers(-6, 7)) - 0.3
+        a, b, th = float(rng.uniform(24, 96)) / top, float(rng.uniform(12, 48)) / top, float(rng.uniform(0, np.pi))
+        ew = 2 * int(np.ceil(max(a, b))) + 1
+        area = (int(round(px / top)) - ew // 2, int(round(py / top)) - ew // 2, ew, ew)
+        jobs.append(dict(frame=0, proj=proj, proj_mask=mask, px=px, py=py, threshold=0.9, stride=3,
+                         coarse_area=area, coarse_mask=synth.ellipse_mask(ew, ew, a, b, th)))
+    return jobs
+
+
+def test_c3_track_walk_with_ellipse_windows(ctx, oracle):
+    """C3 in one launch: 1280x720, pyramid {1,2,4,8}, 256 features with 31x31 masked templates, the coarsest level
+    searched under each feature's rasterised uncertainty ellipse (patchMask + areaMask mode), the finer levels by
+    the reference's radius rule; every walk must equal the oracle's."""
+    w, h, subs = 1280, 720, [1.0, 2.0, 4.0, 8.0]
+    rng = np.random.default_rng(synth.SEED_BASE + 3)
+    shift = (5, -4)
+    f0, f1 = synth.frame(w, h, synth.SEED_BASE + 33), synth.frame(w, h, synth.SEED_BASE + 33, shift)
+    jobs = _c3_jobs(rng, w, h, subs, 256, 31, f0, shift)
+    jobs.append(dict(jobs[0], coarse_mask=None))                                        # window without a mask
+    jobs.append(dict(jobs[1], coarse_area=(-3, -2, 9, 7), coarse_mask=np.ones((7, 9), np.uint8)))   # over the corner
+    jobs.append(dict(jobs[2], coarse_mask=np.zeros_like(jobs[2]["coarse_mask"])))       # empty mask: nothing visited
+    pyr = api.ImagePyramid(ctx, f1, subs)
+    try:
+        got = api.track_batch(ctx, pyr, jobs)
+    finally:
+        pyr.close()
+    levels = oracle.pyramid(f1, subs)
+    full = 0
+    for j, g in zip(jobs, got):
+        r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"],
+                         coarse_area=j["coarse_area"], coarse_mask=j["coarse_mask"])
+        assert g["status"] == 0
+        assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"]), (j["coarse_area"], g, r)
+        assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+        full += r["levels_run"] == 4
+    assert full >= 100
