@@ -92,6 +92,7 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
     Norms nm = make_norms(0);
     FastState fs;
     fs.valid = false;
+    STAMP(3);
     const bool use_fast = !force_direct && fast_supported(g, lp);
     if (use_fast) fast_search(g, t, scores, lds, lp, refine_always, refine_below, spfull, nm, b, fs STAMP_PASS);
     else {
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void line_track_kernel(sla
     float response = -1.f, sdx = 0.f, sdy = 0.f;
     bool failed = false;
     float lastsub = 1.f;
+    STAMP_DECL;
     for (int i = pyr.nlev - 1; i >= 0 && !failed; --i) {
         float sub = 1.f; int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
 #pragma unroll
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void line_track_kernel(sla
         levels_run++;
         if (g.reject) response = -1.f;                        // matching.cpp:26-30
         else {
-            const CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, true, 0.0);
+            const CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, true, 0.0 STAMP_PASS);
             mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
         }
         if (coarsest) {                                       // lineFeature.cpp:130: Point2i *= double rounds to nearest even

@@ -441,6 +441,7 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         else { UR = max(1, TR / 2); BH = max(1, min(BH, TR - UR + 1)); }
     }
     fs.valid = false; fs.big = big;
+    STAMP(4);
     bool first = true, refine = false;
     int nblocks = 0, yb = 0, xb = -o;
     while (true) {
@@ -473,6 +474,7 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         ba.border = max(ba.xb, 0) < g.xl0 || min(ba.xb + ba.strips * FAST_J, g.aw) > g.xl1 || ba.yb < g.yl0 || ba.yb + ba.bh > g.yl1;
         const int URb = refine ? max(1, min(UR, TR - ba.bh + 1)) : UR;     // the 3-row refine block must fit the tile
         const int S = pick_slices(ba.strips * ba.bh, URb);
+        STAMP(5);
         fast_block(g, t, refine ? nullptr : scores, lds, lp, ba, URb, S, G, big, first, !refine, spfull, nm, best STAMP_PASS);
         first = false;
         nblocks++;
