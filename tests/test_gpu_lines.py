@@ -148,3 +148,47 @@ def test_golden_projection_line_newpoint_vectors_on_gpu(ctx):
     kps = api.fast(ctx, f, 20, True)[0][0]
     sel = api.add_new_points(ctx, f, kps, np.array([[100, 100], [320, 180]], np.float32), 40, 30.0, 10, 10, want_descriptors=False)["sel"]
     assert np.array_equal(sel, gold["newpoints/sel"])
+
+
+def test_line_track_random_shapes_against_oracle(ctx, oracle):
+    """Differential test of the line walk over odd image sizes, fractional pyramid factors, non-square descriptors
+    (down to 1x1: some levels resize to nothing), areas partly or wholly off the image, empty and full masks,
+    strides 1..4 and thresholds that end the walk at every level."""
+    rng = np.random.default_rng(777)
+    nbad = 0
+    for trial in range(10):
+        w, h = int(rng.integers(60, 400)), int(rng.integers(60, 300))
+        subs = [[1.0, 2.0], [1.0], [1.0, 3.0], [1.0, 1.5, 2.5], [1.0, 2.0, 4.0]][trial % 5]
+        top = subs[-1]
+        f0 = synth.frame(w, h, 900 + trial)
+        f1 = synth.frame(w, h, 900 + trial, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))))
+        jobs = []
+        for k in range(24):
+            dw, dh = min(int(rng.integers(1, 70)), w), min(int(rng.integers(1, 70)), h)
+            cx, cy = int(rng.integers(dw // 2, w - (dw - dw // 2) + 1)), int(rng.integers(dh // 2, h - (dh - dh // 2) + 1))
+            d = f0[cy - dh // 2:cy - dh // 2 + dh, cx - dw // 2:cx - dw // 2 + dw].copy()
+            aw, ah = int(rng.integers(1, 50)), int(rng.integers(1, 40))
+            ax, ay = int(cx / top) - aw // 2 + int(rng.integers(-6, 7)), int(cy / top) - ah // 2 + int(rng.integers(-6, 7))
+            if k % 8 == 0:
+                ax, ay = int(rng.choice([-aw - 3, -aw // 2, int(w / top) - 2, int(w / top) + 9])), int(rng.choice([-ah // 2, int(h / top) - 1]))
+            kind = k % 3
+            am = (np.full((ah, aw), 255, np.uint8) if kind == 0 else np.zeros((ah, aw), np.uint8) if (kind == 1 and k % 2)
+                  else oracle.disc_mask(aw, ah, np.stack([rng.integers(0, aw, 4), rng.integers(0, ah, 4), rng.integers(0, 12, 4)], 1)))
+            jobs.append(dict(frame=0, descriptor=d, area=(ax, ay, aw, ah), area_mask=am,
+                             threshold=float(rng.choice([-5.0, 0.5, 0.9, 1.6])), stride=int(rng.integers(1, 5))))
+        pyr = api.ImagePyramid(ctx, f1, subs)
+        try:
+            got = api.line_track_batch(ctx, pyr, jobs)
+        finally:
+            pyr.close()
+        levels = oracle.pyramid(f1, subs)
+        for j, g in zip(jobs, got):
+            r = oracle.line_track(levels, subs, j["descriptor"], j["area"], j["area_mask"], j["threshold"], j["stride"])
+            same = g["status"] == 0 and (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"])
+            for key in ("response", "dx", "dy"):
+                a, b = np.float32(g[key]), np.float32(r[key])
+                same = same and ((np.isnan(a) and np.isnan(b)) or a.view(np.uint32) == b.view(np.uint32))
+            if not same:
+                nbad += 1
+                print("trial", trial, subs, j["descriptor"].shape, j["area"], j["threshold"], j["stride"], g, r)
+    assert nbad == 0

@@ -486,3 +486,45 @@ def test_c3_track_walk_with_ellipse_windows(ctx, oracle):
         assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
         full += r["levels_run"] == 4
     assert full >= 100
+
+
+def test_track_random_shapes_against_oracle(ctx, oracle):
+    """Differential test over shapes the fixed configurations do not reach: odd image sizes, fractional pyramid
+    factors, non-square and tiny templates (down to 1x1, where coarse levels resize to nothing), random masks,
+    strides 1..5, predictions on and beyond the image border, thresholds that stop the walk at every level."""
+    rng = np.random.default_rng(2026)
+    nbad = 0
+    for trial in range(12):
+        w, h = int(rng.integers(40, 400)), int(rng.integers(40, 300))
+        subs = [[1.0], [1.0, 2.0], [1.0, 3.0], [1.0, 1.5, 2.5], [1.0, 2.0, 4.0, 8.0], [2.0, 5.0]][trial % 6]
+        f0 = synth.frame(w, h, 500 + trial)
+        f1 = synth.frame(w, h, 500 + trial, (int(rng.integers(-4, 5)), int(rng.integers(-4, 5))))
+        jobs = []
+        for k in range(40):
+            pw, ph = int(rng.integers(1, 48)), int(rng.integers(1, 48))
+            pw, ph = min(pw, w), min(ph, h)
+            cx, cy = int(rng.integers(pw // 2, w - (pw - pw // 2) + 1)), int(rng.integers(ph // 2, h - (ph - ph // 2) + 1))
+            proj = f0[cy - ph // 2:cy - ph // 2 + ph, cx - pw // 2:cx - pw // 2 + pw].copy()
+            kind = k % 4
+            mask = (np.ones_like(proj) if kind == 0 else rng.integers(0, 2, proj.shape, dtype=np.uint8) if kind == 1
+                    else np.zeros_like(proj) if kind == 2 else (rng.random(proj.shape) < 0.9).astype(np.uint8))
+            px = float(cx + rng.integers(-12, 13)) + float(rng.random())
+            py = float(cy + rng.integers(-12, 13)) + float(rng.random())
+            if k % 7 == 0:
+                px, py = float(rng.choice([-30.0, -2.5, 0.0, w - 1.0, w + 25.0])), float(rng.choice([-30.0, 0.4, h - 0.6, h + 40.0]))
+            jobs.append(dict(frame=0, proj=proj, proj_mask=mask, px=px, py=py,
+                             threshold=float(rng.choice([-5.0, 0.3, 0.9, 0.98, 1.5])), stride=int(rng.integers(1, 6))))
+        pyr = api.ImagePyramid(ctx, f1, subs)
+        try:
+            got = api.track_batch(ctx, pyr, jobs)
+        finally:
+            pyr.close()
+        levels = oracle.pyramid(f1, subs)
+        for j, g in zip(jobs, got):
+            r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+            same = g["status"] == 0 and (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"]) and \
+                _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+            if not same:
+                nbad += 1
+                print("trial", trial, subs, j["proj"].shape, j["px"], j["py"], j["threshold"], j["stride"], g, r)
+    assert nbad == 0
