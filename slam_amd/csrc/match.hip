@@ -93,6 +93,10 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
     FastState fs;
     fs.valid = false;
     STAMP(3);
+    if (!force_direct && !scores) {                    // small all-interior level: one lane group per cell
+        MiniPlan mp;
+        if (mini_supported(g, t, lp.acc_bytes + lp.tmpl_bytes + lp.tile_bytes, mp)) return mini_level(g, t, lds, mp, refine_always, refine_below STAMP_PASS);
+    }
     const bool use_fast = !force_direct && fast_supported(g, lp);
     if (use_fast) fast_search(g, t, scores, lds, lp, refine_always, refine_below, spfull, nm, b, fs STAMP_PASS);
     else {

@@ -152,6 +152,90 @@ __device__ __forceinline__ Walk2D make_walk(int width, int rows) {
     return w;
 }
 
+// Stages template rows [u0, u0 + ur) into LDS as {P0 = patch*mask, mask = 0xFF per kept pixel} entries of 8 bytes per
+// 4-pixel group (G groups per row), resizing the template on the fly when the level needs it
+// (feature.cpp:130-131), and adds the rows' |P0|^2 to sp_part.  `taps_region` (taps_bytes of LDS that nothing
+// else uses until this returns) holds the tap tables of the resize.  Ends with the staged rows NOT yet visible
+// to other lanes: the caller synchronises.
+__device__ __forceinline__ void stage_template(const Geo& g, const Tmpl& t, lds_u64* tmpl, lds_u64* taps_region, int taps_bytes,
+                                               int u0, int ur, int G, unsigned long long& sp_part) {
+    const int lane = threadIdx.x;
+    {
+    // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
+    const int ntap = G * 4 + ur;                       // column taps then row taps, 8 bytes each
+    if (t.resized && ntap * 8 <= taps_bytes) {
+        // cv::resize of the template on the fly (feature.cpp:130-131).  The tap tables of this
+        // chunk go to LDS first (the tile region is still free), then every lane produces one
+        // template pixel at a time: 4 source bytes of the patch, 4 of the mask, fixed-point blend.
+        lds_u64* taps = taps_region;
+        for (int i = lane; i < ntap; i += SLAM_WG) {
+            int o, c0, c1;
+            if (i < G * 4) resize_tap(min(i, g.pw - 1), t.scale_x, t.srcw, true, o, c0, c1);
+            else resize_tap(u0 + (i - G * 4), t.scale_y, t.srch, false, o, c0, c1);
+            taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)o;
+        }
+        __syncthreads();
+        lds_u8* tb = reinterpret_cast<lds_u8*>(tmpl);
+        const int wpx = G * 4;
+        const float rw = __builtin_amdgcn_rcpf((float)wpx);
+        for (int i = lane; i < ur * wpx; i += SLAM_WG) {
+            const int u = (int)(((float)i + 0.5f) * rw), v = i - u * wpx;
+            unsigned p = 0, m = 0;
+            if (v < g.pw) {
+                const unsigned long long tx = taps[v], ty = taps[wpx + u];
+                const int sx = (int)(unsigned)tx, sy = (int)(unsigned)ty;
+                const int a0 = (short)(tx >> 32), a1 = (short)(tx >> 48), b0 = (short)(ty >> 32), b1 = (short)(ty >> 48);
+                m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, true) != 0) : 1u;
+                p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, false) * m;
+            }
+            sp_part += p * p;
+            const int e = (u * G + (v >> 2)) * 8 + (v & 3);        // byte of the {P0, mask} entry
+            tb[e] = (unsigned char)p;
+            tb[e + 4] = m ? 0xFF : 0x00;
+        }
+        __syncthreads();                               // the taps are dead before the tile is staged over them
+    } else {
+        const Walk2D w = make_walk(G, ur);
+        for (int gg = w.c0; gg < G; gg += w.cstep) {
+            const int nb = min(4, g.pw - gg * 4);      // pixels of this group inside the template
+            const unsigned keep = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+            if (!t.resized) {
+                for (int u = w.r0; u < ur; u += w.rstep) {
+                    const long long o = (long long)(u0 + u) * t.srcw + gg * 4;
+                    const unsigned P = load4(t.patch + o, t.limit);
+                    const unsigned Mraw = t.mask ? load4(t.mask + o, t.limit) : 0x01010101u;
+                    // per byte: non-zero -> 0xFF
+                    const unsigned nz = (((Mraw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | Mraw) & 0x80808080u;
+                    const unsigned M = ((nz >> 7) * 0xFFu) & keep;
+                    const unsigned P0 = P & M;
+                    sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
+                    tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
+                }
+            } else {
+                int sx[4], a0[4], a1[4];               // the column taps do not depend on the row
+#pragma unroll
+                for (int b = 0; b < 4; b++) resize_tap(min(gg * 4 + b, g.pw - 1), t.scale_x, t.srcw, true, sx[b], a0[b], a1[b]);
+                for (int u = w.r0; u < ur; u += w.rstep) {
+                    int sy, b0, b1;
+                    resize_tap(u0 + u, t.scale_y, t.srch, false, sy, b0, b1);
+                    unsigned P0 = 0, M = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const unsigned m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx[b], a0[b], a1[b], sy, b0, b1, true) != 0) : 1u;
+                        const unsigned p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx[b], a0[b], a1[b], sy, b0, b1, false) * m;
+                        P0 |= p << (8 * b);
+                        M |= (m ? 0xFFu : 0u) << (8 * b);
+                    }
+                    P0 &= keep; M &= keep;
+                    sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
+                    tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
+                }
+            }
+        }
+    }
+    }
+}
+
 // One block of cells [xb, xb + 4*strips) x [yb, yb+bh) (xb may be < 0: columns left of 0 and right
 // of aw are padding): sums into acc, then (update) scores into the running argmax / score map.
 __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* scores, lds_u8* lds, const LdsPlan& lp,
@@ -179,78 +263,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         const int ur = min(UR, g.ph - u0);
         __syncthreads();                                   // previous chunk's readers are done
         STAMP(10);
-        // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
-        const int ntap = G * 4 + ur;                       // column taps then row taps, 8 bytes each
-        if (t.resized && ntap * 8 <= lp.tile_bytes) {
-            // cv::resize of the template on the fly (feature.cpp:130-131).  The tap tables of this
-            // chunk go to LDS first (the tile region is still free), then every lane produces one
-            // template pixel at a time: 4 source bytes of the patch, 4 of the mask, fixed-point blend.
-            lds_u64* taps = reinterpret_cast<lds_u64*>(tile);
-            for (int i = lane; i < ntap; i += SLAM_WG) {
-                int o, c0, c1;
-                if (i < G * 4) resize_tap(min(i, g.pw - 1), t.scale_x, t.srcw, true, o, c0, c1);
-                else resize_tap(u0 + (i - G * 4), t.scale_y, t.srch, false, o, c0, c1);
-                taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)o;
-            }
-            __syncthreads();
-            lds_u8* tb = reinterpret_cast<lds_u8*>(tmpl);
-            const int wpx = G * 4;
-            const float rw = __builtin_amdgcn_rcpf((float)wpx);
-            for (int i = lane; i < ur * wpx; i += SLAM_WG) {
-                const int u = (int)(((float)i + 0.5f) * rw), v = i - u * wpx;
-                unsigned p = 0, m = 0;
-                if (v < g.pw) {
-                    const unsigned long long tx = taps[v], ty = taps[wpx + u];
-                    const int sx = (int)(unsigned)tx, sy = (int)(unsigned)ty;
-                    const int a0 = (short)(tx >> 32), a1 = (short)(tx >> 48), b0 = (short)(ty >> 32), b1 = (short)(ty >> 48);
-                    m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, true) != 0) : 1u;
-                    p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, false) * m;
-                }
-                sp_part += p * p;
-                const int e = (u * G + (v >> 2)) * 8 + (v & 3);        // byte of the {P0, mask} entry
-                tb[e] = (unsigned char)p;
-                tb[e + 4] = m ? 0xFF : 0x00;
-            }
-            __syncthreads();                               // the taps are dead before the tile is staged over them
-        } else {
-            const Walk2D w = make_walk(G, ur);
-            for (int gg = w.c0; gg < G; gg += w.cstep) {
-                const int nb = min(4, g.pw - gg * 4);      // pixels of this group inside the template
-                const unsigned keep = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
-                if (!t.resized) {
-                    for (int u = w.r0; u < ur; u += w.rstep) {
-                        const long long o = (long long)(u0 + u) * t.srcw + gg * 4;
-                        const unsigned P = load4(t.patch + o, t.limit);
-                        const unsigned Mraw = t.mask ? load4(t.mask + o, t.limit) : 0x01010101u;
-                        // per byte: non-zero -> 0xFF
-                        const unsigned nz = (((Mraw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | Mraw) & 0x80808080u;
-                        const unsigned M = ((nz >> 7) * 0xFFu) & keep;
-                        const unsigned P0 = P & M;
-                        sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
-                        tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
-                    }
-                } else {
-                    int sx[4], a0[4], a1[4];               // the column taps do not depend on the row
-#pragma unroll
-                    for (int b = 0; b < 4; b++) resize_tap(min(gg * 4 + b, g.pw - 1), t.scale_x, t.srcw, true, sx[b], a0[b], a1[b]);
-                    for (int u = w.r0; u < ur; u += w.rstep) {
-                        int sy, b0, b1;
-                        resize_tap(u0 + u, t.scale_y, t.srch, false, sy, b0, b1);
-                        unsigned P0 = 0, M = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; b++) {
-                            const unsigned m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx[b], a0[b], a1[b], sy, b0, b1, true) != 0) : 1u;
-                            const unsigned p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx[b], a0[b], a1[b], sy, b0, b1, false) * m;
-                            P0 |= p << (8 * b);
-                            M |= (m ? 0xFFu : 0u) << (8 * b);
-                        }
-                        P0 &= keep; M &= keep;
-                        sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
-                        tmpl[u * G + gg] = ((unsigned long long)M << 32) | P0;
-                    }
-                }
-            }
-        }
+        stage_template(g, t, tmpl, reinterpret_cast<lds_u64*>(tile), lp.tile_bytes, u0, ur, G, sp_part);
         STAMP(11);
         // ---- stage the image tile (and its validity) --------------------------------------------
         {
@@ -481,6 +494,157 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         fs.ba = ba;
         if (refine) { fs.valid = true; break; }
     }
+}
+
+// ---- small levels: one lane group per cell ------------------------------------------------------
+// The coarse levels of a walk score a handful of cells with a small template; the block machinery above
+// (strips, row slices, LDS accumulators, block planning) costs far more than their arithmetic.  When every
+// cell's patch lies inside the image, the level visits at most 64 cells and template, tile and tap tables fit
+// the job's LDS, the level is searched here instead: template and image tile are staged as above, each visited
+// cell gets P = 2^k lanes that split the template rows, partial sums meet by butterfly shuffles, and every
+// lane of a cell evaluates the cell's score.  Same integer sums, same formulas, same argmax rule.
+struct MiniPlan { int nx, ny, step, parts, G, tp, trows, o; };
+
+__device__ __forceinline__ bool mini_supported(const Geo& g, const Tmpl& t, int lds_total, MiniPlan& mp) {
+    const int G = (g.pw + 3) >> 2;
+    const bool interior = g.xl0 == 0 && g.yl0 == 0 && g.xl1 == g.aw && g.yl1 == g.ah;
+    if (!interior || g.aw > 64 || g.ah > 64 || G > 16 || g.ph > 64) return false;
+    const int step = g.masked ? g.stride : 1;          // without a patch mask every interior cell is visited (matching.cpp:151-153)
+    const int nx = step == 1 ? g.aw : small_div_u(g.aw + step - 1, step);
+    const int ny = step == 1 ? g.ah : small_div_u(g.ah + step - 1, step);
+    const int ncell = nx * ny;
+    if (ncell > 64) return false;
+    const bool aligned = ((reinterpret_cast<unsigned long long>(g.im) | (unsigned long long)g.ipitch) & 3ull) == 0;
+    const int o = g.x0 & 3;
+    const int tp = ((o + g.aw + 4 * G + 3) >> 2) | 1;  // dwords per tile row: every cell's G dwords plus the one after them
+    const int trows = g.ah + g.ph - 1;
+    const int tile_bytes = trows * tp * 4, tmpl_bytes = g.ph * G * 8, tap_bytes = t.resized ? (G * 4 + g.ph) * 8 : 0;
+    if (!aligned || (g.x0 - o) + 4 * tp > g.w) return false;   // the tile's dword rows must lie inside the image rows
+    if (tmpl_bytes + max(tile_bytes, tap_bytes) > lds_total) return false;
+    mp.nx = nx; mp.ny = ny; mp.step = step; mp.G = G; mp.tp = tp; mp.trows = trows; mp.o = o;
+    mp.parts = ncell <= 4 ? 16 : ncell <= 8 ? 8 : ncell <= 16 ? 4 : ncell <= 32 ? 2 : 1;
+    return true;
+}
+
+// parabola through the peak s and its two neighbours on one axis (not in the reference); 0 when a neighbour
+// is missing, unvisited (-1) or NaN, or the three values are not strictly concave
+__device__ __forceinline__ float subpixel_axis(float s, float a, float b, bool oka, bool okb) {
+    if (!(oka && okb && a != -1.f && b != -1.f && a == a && b == b)) return 0.f;
+    const float d2 = __fsub_rn(__fadd_rn(a, b), __fmul_rn(2.0f, s));
+    if (!(d2 < 0.f)) return 0.f;
+    const float q = __fdiv_rn(__fsub_rn(a, b), __fmul_rn(2.0f, d2));
+    return q < -0.5f ? -0.5f : (q > 0.5f ? 0.5f : q);
+}
+
+__device__ __forceinline__ CoreOut mini_level(const Geo& g, const Tmpl& t, lds_u8* lds, const MiniPlan& mp,
+                                              bool refine_always, double refine_below STAMP_ARG) {
+    const int lane = threadIdx.x;
+    const int G = mp.G, tp = mp.tp;
+    lds_u64* tmpl = reinterpret_cast<lds_u64*>(lds);
+    lds_u32* tile = reinterpret_cast<lds_u32*>(lds + g.ph * G * 8);
+    unsigned long long sp_part = 0;
+    __syncthreads();                                   // earlier readers of this LDS are done
+    stage_template(g, t, tmpl, reinterpret_cast<lds_u64*>(tile), t.resized ? (G * 4 + g.ph) * 8 : 0, 0, g.ph, G, sp_part);
+    STAMP(40);
+    {   // image tile: rows y0 .. y0 + ah + ph - 2, dword columns from (x0 & ~3); all inside the image
+        const uint8_t* base = g.im + (long long)g.y0 * g.ipitch + (g.x0 - mp.o);
+        const int n = mp.trows * tp;
+        const float rtp = __builtin_amdgcn_rcpf((float)tp);
+        for (int i0 = lane; i0 < n; i0 += 4 * SLAM_WG) {
+            unsigned v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = min(i0 + q * SLAM_WG, n - 1);
+                const int r = (int)(((float)i + 0.5f) * rtp), c = i - r * tp;
+                v[q] = *reinterpret_cast<const unsigned*>(base + (long long)r * g.ipitch + 4 * c);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i0 + q * SLAM_WG < n) tile[i0 + q * SLAM_WG] = v[q];
+        }
+    }
+    // at most 66051 template pixels: the whole sum of squares fits 32 bits
+    const unsigned long long spfull = wave_sum_u32((unsigned)sp_part);
+    const Norms nm = make_norms(spfull);
+    __syncthreads();
+    STAMP(41);
+
+    // lane -> (cell, part)
+    const int P = mp.parts, ncell = mp.nx * mp.ny;
+    const int pshift = P == 16 ? 4 : P == 8 ? 3 : P == 4 ? 2 : P == 2 ? 1 : 0;
+    const int cell = lane >> pshift, part = lane & (P - 1);
+    const bool live = cell < ncell;
+    const int cj = live ? small_div(cell, mp.nx) : 0, ci = live ? cell - cj * mp.nx : 0;
+    const int x = ci * mp.step, y = cj * mp.step;
+    unsigned cc = 0, si = 0;
+    if (live) {
+        const int bx = mp.o + x;
+        const int k = bx & 3;
+        for (int u = part; u < g.ph; u += P) {
+            const lds_u32* tr = tile + (y + u) * tp + (bx >> 2);
+            const lds_u64* pr = tmpl + u * G;
+            unsigned d0 = tr[0];
+            for (int gq = 0; gq < G; ++gq) {
+                const unsigned dn = tr[gq + 1];
+                const unsigned long long pm = pr[gq];
+                const unsigned P0 = (unsigned)pm, M = (unsigned)(pm >> 32);
+                const unsigned w = __builtin_amdgcn_alignbyte(dn, d0, (unsigned)k);
+                const unsigned wm = w & M;
+                cc = __builtin_amdgcn_udot4(w, P0, cc, false);
+                si = __builtin_amdgcn_udot4(wm, wm, si, false);
+                d0 = dn;
+            }
+        }
+    }
+    for (int m = 1; m < P; m <<= 1) {                  // butterfly over the parts of a cell: every part ends with the sums
+        cc += (unsigned)__shfl_xor((int)cc, m, 64);
+        si += (unsigned)__shfl_xor((int)si, m, 64);
+    }
+    STAMP(42);
+    float sc = -1.f;                                   // matching.cpp:53
+    if (live) {
+        const bool am = !g.amask || g.amask[(long long)y * g.ampitch + x] != 0;
+        if (g.masked) { if (am) sc = score_f32_n(cc, si, nm.p2f); }
+        else if (!(g.exact && !am)) sc = score_mt_n(cc, si, nm.tn);
+    }
+    Best b = {-FLT_MAX, INT_MAX};
+    if (live && part == 0) best_update(b, sc, y * g.aw + x);
+    b = best_wave(b);
+    b.idx = __builtin_amdgcn_readfirstlane(b.idx);
+    b.v = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(b.v)));
+    // Visited cells score >= 0 or NaN.  If none scored, the maximum is the -1 of the first cell the
+    // reference never visits (off the lattice): look it up.
+    if (g.stride > 1 && g.masked && !(b.v >= 0.f)) b = first_unvisited(g);
+    STAMP(43);
+    CoreOut o;
+    o.dx = 0.f; o.dy = 0.f;
+    if (b.idx == INT_MAX) {                            // nothing compared greater than -FLT_MAX: every cell is NaN
+        o.x = -1 + g.ax; o.y = -1 + g.ay; o.response = 0.f;
+        return o;
+    }
+    const int ly = row_of_idx(g, b.idx), lx = b.idx - ly * g.aw;
+    o.x = lx + g.ax; o.y = ly + g.ay; o.response = b.v;
+    if (!(refine_always || (double)b.v < refine_below)) return o;
+    // the four neighbours of the peak: a neighbour on the lattice sits in another lane group, one off the
+    // lattice was never visited (-1)
+    float nb[4]; bool in[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int qx = lx + (q == 0 ? -1 : q == 1 ? 1 : 0), qy = ly + (q == 2 ? -1 : q == 3 ? 1 : 0);
+        in[q] = qx >= 0 && qy >= 0 && qx < g.aw && qy < g.ah;
+        float v = -1.f;
+        if (in[q]) {
+            int src = -1;
+            if (mp.step == 1) src = (qy * mp.nx + qx) << pshift;
+            else if (mod_stride(g, qx) == 0 && mod_stride(g, qy) == 0) src = (small_div_u(qy, mp.step) * mp.nx + small_div_u(qx, mp.step)) << pshift;
+            const float got = __shfl(sc, src < 0 ? 0 : src, 64);
+            if (src >= 0) v = got;
+        }
+        nb[q] = v;
+    }
+    o.dx = subpixel_axis(b.v, nb[0], nb[1], in[0], in[1]);
+    o.dy = subpixel_axis(b.v, nb[2], nb[3], in[2], in[3]);
+    return o;
 }
 
 }  // namespace slamdev
