@@ -201,7 +201,7 @@ def fast_leg(api, capi, ctx, stream, dev, args):
     alg = w * h * nfr + 12 * int(np.minimum(cnt, cap).sum())
     return {"workload": "C4: %d frames %dx%d, FAST-9-16 threshold %d + non-max suppression" % (nfr, w, h, thr),
             "value": w * h * nfr / (ms * 1e-3), "unit": "px/s", "ms": ms, "corners_per_frame": float(cnt.mean()),
-            "roofline": {"bound": "hbm", "kernel": "fast_band_kernel+fast_gather_kernel", "achieved": alg / (ms * 1e-3) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "fast_tile_kernel+fast_scan_kernel+fast_scatter_kernel", "achieved": alg / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": alg},
             "parity": parity}

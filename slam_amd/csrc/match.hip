@@ -152,6 +152,14 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
     return o;
 }
 
+// (int)round((double)f) for a float f: C round() (half away from zero) of the same real value; the float is
+// split exactly into trunc and fraction, so single precision gives the identical integer.
+__device__ __forceinline__ int round_f2i(float f) {
+    const float tr = truncf(f);
+    const float fr = __fsub_rn(f, tr);                    // exact: |fr| < 1 and tr share f's exponent range
+    return (int)tr + (fr >= 0.5f ? 1 : 0) - (fr <= -0.5f ? 1 : 0);
+}
+
 // value of lane `i` (wave-uniform index)
 __device__ __forceinline__ int lane_i32(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
 __device__ __forceinline__ float lane_f32(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (l == L) { sub_l = pyr.lev[l].sub; lw_l = pyr.lev[l].w; lh_l = pyr.lev[l].h; lp_l = pyr.lev[l].pitch; ls_l = pyr.lev[l].frame_stride; ld_l = pyr.lev[l].data; }
         if (l == L + 1) subn_l = pyr.lev[l].sub;
     }
+    STAMP(8);
     int tw_l = job.projw, th_l = job.projh;      // feature.cpp:126-128
     double scx_l = 1.0, scy_l = 1.0;
     if (sub_l != 1.f) {                          // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
@@ -278,6 +287,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
             scy_l = resize_scale(job.projh, th_l);
         }
     }
+    STAMP(7);
     float rad_l;
     if (L == pyr.nlev - 1) {
         rad_l = __fdiv_rn(20.f, sub_l);          // feature.cpp:119,134
@@ -285,8 +295,9 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         rad_l = (float)__ddiv_rn(__dmul_rn(1.3, (double)subn_l), (double)sub_l);
         if (L == 0) rad_l = __fmul_rn(rad_l, (float)job.stride);
     }
-    const int rs_l = (int)round((double)__fadd_rn(__fmul_rn(2.f, rad_l), 1.f));   // feature.cpp:146
+    const int rs_l = round_f2i(__fadd_rn(__fmul_rn(2.f, rad_l), 1.f));   // feature.cpp:146
     const double stop_below = __dmul_rn(0.67, (double)job.threshold);           // feature.cpp:151
+    STAMP(6);
 
     float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
     float response = 0.f, sdx = 0.f, sdy = 0.f;
@@ -302,8 +313,8 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
         t.scale_x = lane_f64(scx_l, i); t.scale_y = lane_f64(scy_l, i);
         // feature.cpp:144-146
-        int rx = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(tx, sub), searchRad)));
-        int ry = __builtin_amdgcn_readfirstlane((int)round((double)__fsub_rn(__fdiv_rn(ty, sub), searchRad)));
+        int rx = __builtin_amdgcn_readfirstlane(round_f2i(__fsub_rn(__fdiv_rn(tx, sub), searchRad)));
+        int ry = __builtin_amdgcn_readfirstlane(round_f2i(__fsub_rn(__fdiv_rn(ty, sub), searchRad)));
         int rw = rs, rh = rs;
         const uint8_t* am = nullptr;
         if (coarse_area && i == pyr.nlev - 1) {                  // caller's window and area mask on the coarsest level
@@ -385,8 +396,8 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void line_track_kernel(sla
         float areaRes = 1.f;
         if (coarsest) {
             areaRes = __fdiv_rn(1.f, sub);                                         // lineFeature.cpp:30
-            t.tw = (int)round((double)__fmul_rn(descw, areaRes));                  // lineFeature.cpp:124
-            t.th = (int)round((double)__fmul_rn(desch, areaRes));
+            t.tw = round_f2i(__fmul_rn(descw, areaRes));                  // lineFeature.cpp:124
+            t.th = round_f2i(__fmul_rn(desch, areaRes));
             ax = job.ax; ay = job.ay; aw = job.aw; ah = job.ah; am = blob + job.amask_off; stride = job.stride;
         } else {
             stride = (i == 0) ? 1 : job.stride;                                    // lineFeature.cpp:148-150
