@@ -349,6 +349,48 @@ int slam_hip_match_lines_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_li
                                const uint8_t* desc_blob, size_t desc_bytes, slam_track_result* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * Uncertainty windows — the coarsest-level search window of a feature whose predicted point has a
+ * 2x2 covariance (the EKF's innovation covariance): the gate ellipse
+ *     { p : (p - p2d)^T S^-1 (p - p2d) <= gate }
+ * scaled to the coarsest level, its bounding rectangle and its rasterised area mask, ready for
+ * slam_track_job's SLAM_HIP_TRACK_COARSE_AREA fields.  The reference has no live counterpart: its
+ * windows are the fixed square of feature.cpp:134,144-146 and the disc unions of lineFeature.cpp:86-96;
+ * its density rasteriser SLAM::projectGaussian (new_point.cpp:31-107) is never called.  The rectangle
+ * follows the floor / ceil(+1) convention of lineFeature.cpp:60-63 and the 300-pixel cap of
+ * lineFeature.cpp:27,81-84.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct slam_ellipse_job {
+    int64_t mask_off;                 /* mask in the blob, pitch w; every byte of it is written (0 or 255) */
+    int32_t x, y, w, h;               /* the window, in pixels of the level it was set up for */
+    float   ux, uy;                   /* ellipse centre relative to (x, y) */
+    float   q11, q12, q22;            /* inside <=> q11*dx*dx + 2*q12*dx*dy + q22*dy*dy <= 1 (float, this order) */
+    int32_t valid;                    /* 0: no window (degenerate covariance or larger than the cap) */
+} slam_ellipse_job;
+
+#define SLAM_HIP_ELLIPSE_MAX 300      /* widest / tallest window (lineFeature.cpp:27) */
+
+/* Host-only arithmetic, no device work.  cov = {sxx, sxy, syy} in full-resolution pixels^2, gate =
+ * squared Mahalanobis radius, res = 1 / subsample of the level searched (lineFeature.cpp:30).  Fills
+ * every field of *out except mask_off.  Returns 0, or SLAM_HIP_EINVAL for null pointers; a covariance
+ * that is not positive definite, non-finite input or a window beyond the cap gives valid = 0. */
+int slam_hip_ellipse_setup(float px, float py, const float* cov, float gate, float res, slam_ellipse_job* out);
+
+/* Rasterises the masks of all valid jobs (invalid ones are skipped).  d_status (optional) receives 0 /
+ * SLAM_HIP_EINVAL per job (mask outside the blob, sizes outside 1..SLAM_HIP_ELLIPSE_MAX).
+ * max_pixels: largest w*h of the batch if known, else 0.  Asynchronous, allocates nothing. */
+int slam_hip_ellipse_masks_d(slam_ctx* ctx, const slam_ellipse_job* d_jobs, int njobs, uint8_t* d_blob,
+                             size_t blob_bytes, int32_t* d_status, int max_pixels);
+
+/* Feature::track for a batch of features with uncertainty windows, host tables: windows[i] (from
+ * slam_hip_ellipse_setup at the pyramid's coarsest level; mask_off assigned here) becomes job i's
+ * coarsest-level area and mask; a job whose window is not valid is reported as (-1,-1), response -1,
+ * levels_run 0.  jobs[i].flags / amask_off / ax..ah are overwritten; proj_off / mask_off point into
+ * blob. */
+int slam_hip_track_ellipse_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs,
+                                 const slam_ellipse_job* windows, int njobs, const uint8_t* blob,
+                                 size_t blob_bytes, slam_track_result* out);
+
+/* ---------------------------------------------------------------------------------------------
  * Diagnostics (used by the parity tests; no reference counterpart).
  * ------------------------------------------------------------------------------------------- */
 /* Evaluates the two score formulas of matching.cpp on the device for n triples of exact integer

@@ -42,6 +42,11 @@ class Projection(C.Structure):
     _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int), ("m", C.c_float * 9), ("valid", C.c_int)]
 
 
+class Ellipse(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int), ("ux", C.c_float), ("uy", C.c_float),
+                ("q11", C.c_float), ("q12", C.c_float), ("q22", C.c_float), ("valid", C.c_int)]
+
+
 class PropCase(C.Structure):
     _fields_ = [("w", C.c_int), ("h", C.c_int), ("pw", C.c_int), ("ph", C.c_int),
                 ("xpatch", C.c_int), ("ypatch", C.c_int),
@@ -102,6 +107,10 @@ def lib():
         L.so_warp_perspective_u8.restype = C.c_int
         L.so_disc_mask.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.so_disc_mask.restype = C.c_int
+        L.so_ellipse_setup.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_float, C.POINTER(Ellipse)]
+        L.so_ellipse_setup.restype = C.c_int
+        L.so_ellipse_mask.argtypes = [C.POINTER(Ellipse), C.c_void_p]
+        L.so_ellipse_mask.restype = C.c_int
         L.so_line_track.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_float, C.c_int, C.POINTER(TrackOut)]
@@ -313,6 +322,20 @@ def disc_mask(w, h, circles):
     if lib().so_disc_mask(w, h, c.ctypes.data, len(c), out.ctypes.data) != 0:
         raise ValueError("so_disc_mask: bad arguments")
     return out
+
+
+def ellipse_window(px, py, cov, gate, res):
+    """Gate ellipse of a 2x2 covariance (sxx, sxy, syy) scaled by res: dict(area=(x, y, w, h), mask, q, centre) or
+    None when there is no window (degenerate covariance, beyond the 300-pixel cap)."""
+    c = np.ascontiguousarray(cov, np.float32).reshape(3)
+    e = Ellipse()
+    if lib().so_ellipse_setup(C.c_float(px), C.c_float(py), c.ctypes.data, C.c_float(gate), C.c_float(res), C.byref(e)) != 0:
+        raise ValueError("so_ellipse_setup: bad arguments")
+    if not e.valid:
+        return None
+    m = np.empty((e.h, e.w), np.uint8)
+    lib().so_ellipse_mask(C.byref(e), m.ctypes.data)
+    return dict(area=(e.x, e.y, e.w, e.h), mask=m, q=(e.q11, e.q12, e.q22), centre=(e.ux, e.uy))
 
 
 def line_track(levels, subs, descriptor, area, area_mask, threshold, stride):

@@ -783,6 +783,48 @@ int so_project(const uint8_t* descr, int dw, int dh, ptrdiff_t dpitch, const flo
 /* ------------------------------------------------------------------------------------------ */
 /* tests/test_matching.cpp:13-101 restated                                                    */
 /* ------------------------------------------------------------------------------------------ */
+/* ---- uncertainty windows (build-defined; no live counterpart in the reference) -------------------
+ * Gate ellipse (p - p2d)^T S^-1 (p - p2d) <= gate of a 2x2 covariance S, scaled by res to the level
+ * searched.  The rectangle uses the floor / ceil(+1) convention of lineFeature.cpp:60-63 and the
+ * 300-pixel cap of lineFeature.cpp:27,81-84. */
+int so_ellipse_setup(float px, float py, const float* cov, float gate, float res, so_ellipse* out) {
+    if (!cov || !out) return -1;
+    memset(out, 0, sizeof(*out));
+    double in[7] = {px, py, cov[0], cov[1], cov[2], gate, res};
+    for (int i = 0; i < 7; i++)
+        if (isnan(in[i]) || isinf(in[i])) return 0;
+    double a = cov[0], b = cov[1], d = cov[2];
+    double det = a * d - b * b;
+    if (gate <= 0.f || res <= 0.f || a <= 0.0 || d <= 0.0 || det <= 0.0) return 0;
+    double r = res, cx = (double)px * r, cy = (double)py * r;
+    double hx = sqrt((double)gate * a) * r, hy = sqrt((double)gate * d) * r;
+    if (!(fabs(cx) + hx < 1e9 && fabs(cy) + hy < 1e9)) return 0;
+    int xmin = (int)floor(cx - hx), ymin = (int)floor(cy - hy);
+    int xmax = (int)ceil(cx + hx) + 1, ymax = (int)ceil(cy + hy) + 1;
+    if (xmax - xmin > 300 || ymax - ymin > 300) return 0;
+    double s = (double)gate * det * r * r;
+    out->x = xmin; out->y = ymin; out->w = xmax - xmin; out->h = ymax - ymin;
+    out->ux = (float)(cx - xmin); out->uy = (float)(cy - ymin);
+    out->q11 = (float)(d / s); out->q12 = (float)(-b / s); out->q22 = (float)(a / s);
+    out->valid = 1;
+    return 0;
+}
+
+int so_ellipse_mask(const so_ellipse* e, uint8_t* mask) {
+    if (!e || !mask || !e->valid || e->w < 1 || e->h < 1) return -1;
+    const float q12x2 = e->q12 + e->q12;
+    for (int y = 0; y < e->h; y++)
+        for (int x = 0; x < e->w; x++) {
+            const float dx = (float)x - e->ux, dy = (float)y - e->uy;
+            const float t0 = (e->q11 * dx) * dx;
+            const float t1 = (q12x2 * dx) * dy;
+            const float t2 = (e->q22 * dy) * dy;
+            const float t = (t0 + t1) + t2;
+            mask[(size_t)y * e->w + x] = t <= 1.f ? 255 : 0;
+        }
+    return 0;
+}
+
 
 /* glibc's rand() (the TYPE_3 additive feedback generator r[i] = r[i-3] + r[i-31], seeded through
  * the 16807 Lehmer generator, first 310 outputs discarded), kept in private state: the trial stream

@@ -15,6 +15,7 @@
  *   feature.cpp:36-51         Feature::newDescriptor crop  -> so_extract_descriptor
  *   feature.cpp:53-100        SLAM::Feature::project       -> so_project_setup, so_warp_perspective_u8
  *   lineFeature.cpp:86-165    LineFeature::track searches  -> so_disc_mask, so_line_track
+ *   (build-defined)           gate-ellipse search windows  -> so_ellipse_setup, so_ellipse_mask
  *   tests/test_matching.cpp   property test generator      -> so_proptest_*
  *
  * The arithmetic of cv::resize, cv::matchTemplate, cv::norm / Mat::dot / Mat::mul,
@@ -158,6 +159,19 @@ int so_warp_perspective_u8(const uint8_t* src, int sw, int sh, ptrdiff_t spitch,
 /* The whole of feature.cpp:53-100: proj and mask (pitch out->w) must hold cap bytes each. */
 int so_project(const uint8_t* descr, int dw, int dh, ptrdiff_t dpitch, const float* P, const float* B, const float* p3d,
                uint8_t* proj, uint8_t* mask, size_t cap, so_projection* out);
+
+/* Uncertainty window of a prediction with a 2x2 covariance cov = {sxx, sxy, syy} (full-resolution
+ * pixels^2): gate ellipse scaled by res, its rectangle and quadratic form.  Build-defined: the reference
+ * has no live counterpart (SLAM::projectGaussian, new_point.cpp:31-107, is never called). */
+typedef struct so_ellipse {
+    int x, y, w, h;
+    float ux, uy;          /* centre relative to (x, y) */
+    float q11, q12, q22;   /* inside <=> q11 dx^2 + 2 q12 dx dy + q22 dy^2 <= 1, evaluated in float */
+    int valid;
+} so_ellipse;
+int so_ellipse_setup(float px, float py, const float* cov, float gate, float res, so_ellipse* out);
+/* mask (pitch e->w) = 255 inside, 0 outside.  Returns 0 / -1 (invalid window). */
+int so_ellipse_mask(const so_ellipse* e, uint8_t* mask);
 
 /* ---- tests/test_matching.cpp:13-101 restated: generator + acceptance rule ------------------- */
 typedef struct so_proptest_case {

@@ -259,6 +259,44 @@ def main():
     out["c3_track_65536x31x31_ellipse"] = {"ms_track": ms, "ms_pyramid": ms_p, "jobs": nfr * nfeat, "frames": nfr,
                                            "all_levels": float((res[:, 5] == 4).mean()), "frames/s": nfr / ((ms + ms_p) * 1e-3),
                                            "features/s": nfr * nfeat / ((ms + ms_p) * 1e-3)}
+    # the same C3 walk with the windows derived from 2x2 covariances (gate 9: semi-axes a, b as above) and the masks
+    # rasterised on the device: slam_hip_ellipse_setup (host) + slam_hip_ellipse_masks_d + slam_hip_track_batch_d
+    ej = (capi.EllipseJob * (nfr * nfeat))()
+    base = 2 * ts * ts * nfeat
+    woff, wins = base, []
+    for k, (po, mo, ao, ew, px, py, _) in enumerate(feats):
+        a, b, th = float(rng.uniform(24, 96)), float(rng.uniform(12, 48)), float(rng.uniform(0, np.pi))
+        c, sn = np.cos(th), np.sin(th)
+        S = np.array([[c, -sn], [sn, c]]) @ np.diag([a * a / 9, b * b / 9]) @ np.array([[c, sn], [-sn, c]])
+        wins.append(api.ellipse_setup(px, py, [S[0, 0], S[0, 1], S[1, 1]], 9.0, 1.0 / 8))
+        assert wins[-1].valid
+    tparts = []
+    for k, (po, mo, ao, ew, px, py, _) in enumerate(feats):
+        tparts += [parts[3 * k], parts[3 * k + 1]]
+    mask_px = 0
+    for f in range(nfr):
+        for k, (po, mo, ao, ew, px, py, _) in enumerate(feats):
+            i = f * nfeat + k
+            ej[i] = wins[k]
+            ej[i].mask_off = woff
+            t = tj[i]
+            t.proj_off, t.mask_off, t.amask_off = 2 * ts * ts * k, 2 * ts * ts * k + ts * ts, woff
+            t.ax, t.ay, t.aw, t.ah = wins[k].x, wins[k].y, wins[k].w, wins[k].h
+            woff += wins[k].w * wins[k].h
+            mask_px += wins[k].w * wins[k].h
+    d_blob2 = torch.zeros(woff + 64, dtype=torch.uint8, device=dev)
+    d_blob2[:base] = torch.from_numpy(np.concatenate(tparts)).to(dev)
+    d_ej = torch.from_numpy(np.frombuffer(bytes(ej), np.uint8).copy()).to(dev)
+    d_tj2 = torch.from_numpy(np.frombuffer(bytes(tj), np.uint8).copy()).to(dev)
+    max_px = max(wn.w * wn.h for wn in wins)
+    ms_e = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_ellipse_masks_d(ctx.handle, P(d_ej), nfr * nfeat, P(d_blob2), woff, None, max_px)))
+    ms_t = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_tj2), nfr * nfeat, P(d_blob2), woff, P(d_res))))
+    res = d_res.cpu().numpy().view(np.int32).reshape(-1, 7)
+    alg_e = mask_px + 48 * nfr * nfeat
+    out["c3_covariance_windows_65536"] = {"ms_masks": ms_e, "mask_bytes": mask_px, "GB/s": alg_e / (ms_e * 1e-3) / 1e9,
+                                          "frac_hbm": alg_e / (ms_e * 1e-3) / 8e12, "ms_track": ms_t,
+                                          "all_levels": float((res[:, 5] == 4).mean()),
+                                          "frames/s": nfr / ((ms_e + ms_t + ms_p) * 1e-3)}
     pyr.close()
     print(json.dumps(out, indent=1))
     ctx.close()

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import (KeyPoint, LevelDesc, MatchJob, MatchResult, SlamHipError, TrackJob, TrackResult,
+from .capi import (EllipseJob, KeyPoint, LevelDesc, MatchJob, MatchResult, SlamHipError, TrackJob, TrackResult,
                    check, lib)
 
 
@@ -223,10 +223,13 @@ def match_batch(ctx, pyr, jobs):
 def track_batch(ctx, pyr, jobs):
     """jobs: list of dicts(frame, proj, proj_mask, px, py, threshold, stride) -> Feature::track results.
     Optional per job: coarse_area=(x, y, w, h) and coarse_mask (or None): the coarsest level is searched in that
-    window under that area mask instead of the reference's fixed square (SLAM_HIP_TRACK_COARSE_AREA)."""
+    window under that area mask instead of the reference's fixed square (SLAM_HIP_TRACK_COARSE_AREA); or
+    window=ellipse_setup(...) on every job: the masks are rasterised on the device (slam_hip_track_ellipse_batch)."""
     n = len(jobs)
     blob = Blob()
     arr = (TrackJob * max(n, 1))()
+    win = (EllipseJob * max(n, 1))()
+    nwin = 0
     for i, j in enumerate(jobs):
         a = arr[i]
         a.frame = j.get("frame", 0)
@@ -251,11 +254,55 @@ def track_batch(ctx, pyr, jobs):
             if cm is not None and _u8(cm).shape != (a.ah, a.aw):
                 raise ValueError("coarse mask shape")
             a.amask_off = blob.add(cm)
+        if j.get("window") is not None:
+            win[i] = j["window"]
+            nwin += 1
     b = blob.bytes()
     res = (TrackResult * max(n, 1))()
-    check(ctx.handle, lib().slam_hip_track_batch(ctx.handle, pyr.handle, arr, n, b.ctypes.data, b.size, res))
+    if nwin:
+        if nwin != n:
+            raise ValueError("either every job carries an uncertainty window or none does")
+        check(ctx.handle, lib().slam_hip_track_ellipse_batch(ctx.handle, pyr.handle, arr, win, n, b.ctypes.data, b.size, res))
+    else:
+        check(ctx.handle, lib().slam_hip_track_batch(ctx.handle, pyr.handle, arr, n, b.ctypes.data, b.size, res))
     return [dict(x=r.x, y=r.y, response=r.response, dx=r.dx, dy=r.dy, levels_run=r.levels_run, status=r.status)
             for r in res[:n]]
+
+
+def ellipse_setup(px, py, cov, gate, res):
+    """Uncertainty window of a prediction (px, py) with covariance cov = (sxx, sxy, syy) in full-resolution pixels^2:
+    the gate ellipse scaled by res = 1 / subsample of the level searched.  Returns an EllipseJob (check .valid);
+    pass it as a track job's "window"."""
+    c = np.ascontiguousarray(cov, np.float32).reshape(3)
+    e = EllipseJob()
+    rc = lib().slam_hip_ellipse_setup(C.c_float(px), C.c_float(py), c.ctypes.data, C.c_float(gate), C.c_float(res), C.byref(e))
+    if rc != 0:
+        raise RuntimeError("slam_hip_ellipse_setup: %d" % rc)
+    return e
+
+
+def ellipse_masks(ctx, windows):
+    """Rasterises the area masks of valid windows on the device; returns a list of arrays (None for invalid ones)."""
+    n = len(windows)
+    arr = (EllipseJob * max(n, 1))()
+    off = 0
+    for i, w in enumerate(windows):
+        arr[i] = w
+        arr[i].mask_off = off
+        off += w.w * w.h if w.valid else 0
+    d_jobs = DeviceBuffer(ctx, host=np.frombuffer(bytes(arr), np.uint8))
+    d_blob = DeviceBuffer(ctx, nbytes=max(off, 1))
+    d_status = DeviceBuffer(ctx, nbytes=4 * max(n, 1))
+    try:
+        check(ctx.handle, lib().slam_hip_ellipse_masks_d(ctx.handle, d_jobs.ptr, n, d_blob.ptr, max(off, 1), d_status.ptr, 0))
+        ctx.synchronize()
+        blob = d_blob.get()
+        st = d_status.get(np.int32)
+    finally:
+        d_jobs.free(); d_blob.free(); d_status.free()
+    if n and st[:n].any():
+        raise RuntimeError("ellipse_masks: a job was rejected by the device")
+    return [blob[a.mask_off:a.mask_off + a.w * a.h].reshape(a.h, a.w).copy() if a.valid else None for a in arr[:n]]
 
 
 def fast(ctx, frames, threshold, nonmax=True, cap=None):

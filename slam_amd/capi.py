@@ -81,6 +81,14 @@ class LineJob(C.Structure):
                 ("stride", C.c_int32), ("reserved", C.c_int32)]
 
 
+class EllipseJob(C.Structure):
+    _fields_ = [("mask_off", C.c_int64), ("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("ux", C.c_float), ("uy", C.c_float), ("q11", C.c_float), ("q12", C.c_float), ("q22", C.c_float),
+                ("valid", C.c_int32)]
+
+
+ELLIPSE_MAX = 300
+
 # every symbol include/slam_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -130,6 +138,9 @@ SIGNATURES = {
     "slam_hip_line_track_batch_d": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "slam_hip_line_track_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "slam_hip_match_lines_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
+    "slam_hip_ellipse_setup": (C.c_int, [C.c_float, C.c_float, _P, C.c_float, C.c_float, C.POINTER(EllipseJob)]),
+    "slam_hip_ellipse_masks_d": (C.c_int, [_P, _P, C.c_int, _P, C.c_size_t, _P, C.c_int]),
+    "slam_hip_track_ellipse_batch": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "slam_hip_debug_score_formulas": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "slam_hip_debug_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int, C.c_size_t]),
     "slam_hip_version": (C.c_char_p, []),

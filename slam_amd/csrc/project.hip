@@ -398,3 +398,128 @@ extern "C" int slam_hip_match_lines_batch(slam_ctx* ctx, const slam_pyr* pyr, co
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return SLAM_HIP_OK;
 }
+
+// ---- uncertainty windows: gate ellipse of a 2x2 covariance -> rectangle + area mask --------------
+extern "C" int slam_hip_ellipse_setup(float px, float py, const float* cov, float gate, float res, slam_ellipse_job* out) {
+    if (!cov || !out) return SLAM_HIP_EINVAL;
+    std::memset(out, 0, sizeof(*out));
+    const double sxx = cov[0], sxy = cov[1], syy = cov[2];
+    if (!std::isfinite(px) || !std::isfinite(py) || !std::isfinite(sxx) || !std::isfinite(sxy) || !std::isfinite(syy) ||
+        !std::isfinite(gate) || !std::isfinite(res))
+        return SLAM_HIP_OK;
+    const double det = sxx * syy - sxy * sxy;
+    if (!(gate > 0.f) || !(res > 0.f) || !(sxx > 0.0) || !(syy > 0.0) || !(det > 0.0)) return SLAM_HIP_OK;
+    const double cx = (double)px * (double)res, cy = (double)py * (double)res;
+    const double hx = std::sqrt((double)gate * sxx) * (double)res, hy = std::sqrt((double)gate * syy) * (double)res;
+    const double lim = 1e9;
+    if (!(std::fabs(cx) + hx < lim) || !(std::fabs(cy) + hy < lim)) return SLAM_HIP_OK;
+    const int x0 = (int)std::floor(cx - hx), y0 = (int)std::floor(cy - hy);
+    const int x1 = (int)std::ceil(cx + hx) + 1, y1 = (int)std::ceil(cy + hy) + 1;
+    if (x1 - x0 > SLAM_HIP_ELLIPSE_MAX || y1 - y0 > SLAM_HIP_ELLIPSE_MAX) return SLAM_HIP_OK;   // lineFeature.cpp:81-84
+    const double s = (double)gate * det * (double)res * (double)res;
+    out->x = x0; out->y = y0; out->w = x1 - x0; out->h = y1 - y0;
+    out->ux = (float)(cx - (double)x0); out->uy = (float)(cy - (double)y0);
+    out->q11 = (float)(syy / s); out->q12 = (float)(-sxy / s); out->q22 = (float)(sxx / s);
+    out->valid = 1;
+    return SLAM_HIP_OK;
+}
+
+namespace {
+
+__global__ __launch_bounds__(WARP_WG) void ellipse_mask_kernel(const slam_ellipse_job* __restrict__ jobs, int njobs,
+                                                               uint8_t* __restrict__ blob, unsigned long long blob_bytes,
+                                                               int32_t* __restrict__ status) {
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_ellipse_job job = jobs[j];
+    const bool lead = blockIdx.y == 0 && threadIdx.x == 0;
+    if (!job.valid) { if (lead && status) status[j] = SLAM_HIP_OK; return; }
+    const bool ok = job.w >= 1 && job.h >= 1 && job.w <= SLAM_HIP_ELLIPSE_MAX && job.h <= SLAM_HIP_ELLIPSE_MAX && job.mask_off >= 0 &&
+                    (unsigned long long)job.mask_off + (unsigned long long)(job.w * job.h) <= blob_bytes;
+    if (lead && status) status[j] = ok ? SLAM_HIP_OK : SLAM_HIP_EINVAL;
+    if (!ok) return;
+    uint8_t* M = blob + job.mask_off;
+    const int total = job.w * job.h;
+    const float q12x2 = __fadd_rn(job.q12, job.q12);
+    for (int i = blockIdx.y * WARP_WG + threadIdx.x; i < total; i += gridDim.y * WARP_WG) {
+        const int y = i / job.w, x = i - y * job.w;
+        const float dx = __fsub_rn((float)x, job.ux), dy = __fsub_rn((float)y, job.uy);
+        const float a = __fmul_rn(__fmul_rn(job.q11, dx), dx);
+        const float b = __fmul_rn(__fmul_rn(q12x2, dx), dy);
+        const float c = __fmul_rn(__fmul_rn(job.q22, dy), dy);
+        M[i] = __fadd_rn(__fadd_rn(a, b), c) <= 1.f ? 255 : 0;
+    }
+}
+
+bool bytes_are_01(const uint8_t* m, size_t n) {
+    uint8_t acc = 0;
+    for (size_t i = 0; i < n; i++) acc |= m[i];
+    return (acc & 0xFE) == 0;
+}
+
+}  // namespace
+
+extern "C" int slam_hip_ellipse_masks_d(slam_ctx* ctx, const slam_ellipse_job* d_jobs, int njobs, uint8_t* d_blob,
+                                        size_t blob_bytes, int32_t* d_status, int max_pixels) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!d_jobs || !d_blob)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "ellipse_masks: null table or negative count");
+    if (njobs == 0) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int slices = max_pixels > 0 ? (max_pixels + WARP_WG * 8 - 1) / (WARP_WG * 8) : 4;
+    slices = std::min(std::max(slices, 1), 64);
+    hipLaunchKernelGGL(ellipse_mask_kernel, dim3(njobs, slices), dim3(WARP_WG), 0, ctx->stream, d_jobs, njobs, d_blob,
+                       (unsigned long long)blob_bytes, d_status);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_track_ellipse_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs,
+                                            const slam_ellipse_job* windows, int njobs, const uint8_t* blob,
+                                            size_t blob_bytes, slam_track_result* out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!jobs || !windows || !blob || !out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_ellipse_batch: null table or negative count");
+    if (!pyr) return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_ellipse_batch: no pyramid");
+    if (njobs == 0) return SLAM_HIP_OK;
+    std::vector<slam_track_job> tj(jobs, jobs + njobs);
+    std::vector<slam_ellipse_job> ej(windows, windows + njobs);
+    size_t off = (blob_bytes + 255) / 256 * 256;
+    int max_pix = 0;
+    for (int i = 0; i < njobs; i++) {
+        slam_track_job& t = tj[i];
+        if (t.projw >= 1 && t.projh >= 1 && t.mask_off >= 0 &&
+            (unsigned long long)t.mask_off + (unsigned long long)t.projw * t.projh <= blob_bytes &&
+            !bytes_are_01(blob + t.mask_off, (size_t)t.projw * t.projh))
+            return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_ellipse_batch: job %d: mask values must be 0 or 1", i);
+        slam_ellipse_job& e = ej[i];
+        const bool live = e.valid && e.w >= 1 && e.h >= 1 && e.w <= SLAM_HIP_ELLIPSE_MAX && e.h <= SLAM_HIP_ELLIPSE_MAX;
+        if (!live) {                                   // no window: reported like an empty projection
+            e.valid = 0; t.projw = 0; t.projh = 0; t.flags = 0;
+            continue;
+        }
+        e.mask_off = (int64_t)off;
+        t.flags = SLAM_HIP_TRACK_COARSE_AREA; t.amask_off = (int64_t)off;
+        t.ax = e.x; t.ay = e.y; t.aw = e.w; t.ah = e.h;
+        off += (size_t)e.w * e.h;
+        max_pix = std::max(max_pix, e.w * e.h);
+    }
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t tb = sizeof(slam_track_job) * (size_t)njobs, eb = sizeof(slam_ellipse_job) * (size_t)njobs;
+    const size_t rb = sizeof(slam_track_result) * (size_t)njobs;
+    const size_t o_e = (tb + 255) / 256 * 256, o_r = o_e + (eb + 255) / 256 * 256;
+    int rc;
+    if ((rc = slam_stage_reserve(ctx, 0, o_r + rb + 16)) || (rc = slam_stage_reserve(ctx, 1, off + 16))) return rc;
+    uint8_t* t0 = (uint8_t*)ctx->d_stage[0];
+    uint8_t* dblob = (uint8_t*)ctx->d_stage[1];
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(t0, tj.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(t0 + o_e, ej.data(), eb, hipMemcpyHostToDevice, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(dblob, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = slam_hip_ellipse_masks_d(ctx, (const slam_ellipse_job*)(t0 + o_e), njobs, dblob, off, nullptr, max_pix);
+    if (rc != SLAM_HIP_OK) return rc;
+    rc = slam_hip_track_batch_d(ctx, pyr, (const slam_track_job*)t0, njobs, dblob, off, (slam_track_result*)(t0 + o_r));
+    if (rc != SLAM_HIP_OK) return rc;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, t0 + o_r, rb, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}

@@ -94,4 +94,4 @@ static_assert(sizeof(slam_track_job) == 72 && sizeof(slam_track_result) == 28, "
 static_assert(sizeof(slam_keypoint) == 12, "ABI struct layout");
 static_assert(sizeof(slam_desc_job) == 32 && sizeof(slam_desc_result) == 20, "ABI struct layout");
 static_assert(sizeof(slam_warp_job) == 80, "ABI struct layout");
-static_assert(sizeof(slam_disc_job) == 24 && sizeof(slam_line_job) == 56, "ABI struct layout");
+static_assert(sizeof(slam_disc_job) == 24 && sizeof(slam_line_job) == 56 && sizeof(slam_ellipse_job) == 48, "ABI struct layout");

@@ -27,6 +27,14 @@ typedef Point_<int> Point2i;
 typedef Point_<float> Point2f;
 typedef Point2i Point;
 
+struct Vec3f {
+    float val[3];
+    Vec3f() : val{0.f, 0.f, 0.f} {}
+    Vec3f(float a, float b, float c) : val{a, b, c} {}
+    float operator[](int i) const { return val[i]; }
+    float& operator[](int i) { return val[i]; }
+};
+
 struct Size {
     int width, height;
     Size() : width(0), height(0) {}

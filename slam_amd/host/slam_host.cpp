@@ -251,6 +251,34 @@ void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Proj
     }
 }
 
+void SLAM::matchPointsGated(const ImagePyramid<byte>& pyramid, const std::vector<Projection>& features,
+                            const std::vector<cv::Vec3f>& covariances, float gate, std::vector<Match>& matches,
+                            float threshold, int stride, std::vector<float>* responses) {
+    matches.clear();
+    if (responses) responses->assign(features.size(), -1.f);
+    if (features.size() != covariances.size()) throw std::invalid_argument("matchPointsGated: one covariance per feature");
+    if (features.empty()) return;
+    std::vector<slam_track_job> jobs;
+    std::vector<uint8_t> blob;
+    pack_jobs(features, threshold, stride, jobs, blob);
+    const float areaRes = 1.f / pyramid.subsamples[pyramid.nSubs() - 1];
+    std::vector<slam_ellipse_job> windows(features.size());
+    for (size_t i = 0; i < features.size(); i++) {
+        const float cov[3] = {covariances[i][0], covariances[i][1], covariances[i][2]};
+        slamhip::check(slam_hip_ellipse_setup(jobs[i].px, jobs[i].py, cov, gate, areaRes, &windows[i]), "matchPointsGated");
+    }
+    std::vector<slam_track_result> res(features.size());
+    slamhip::check(slam_hip_track_ellipse_batch(slamhip::context(), pyramid.device(), jobs.data(), windows.data(),
+                                                (int)jobs.size(), blob.data(), blob.size(), res.data()),
+                   "matchPointsGated");
+    for (size_t i = 0; i < res.size(); i++) {
+        if (res[i].status != SLAM_HIP_OK) throw std::invalid_argument("matchPointsGated: job rejected by the device");
+        if (responses) (*responses)[i] = res[i].response;
+        if (res[i].response > threshold)
+            matches.push_back(Match(cv::Point2f((float)res[i].x, (float)res[i].y), (int)i));
+    }
+}
+
 void SLAM::matchLines(const ImagePyramid<byte>& pyramid, const std::vector<LineSearch>& lines, std::vector<Match>& matches,
                       float threshold, int stride, std::vector<float>* responses) {
     matches.clear();

@@ -114,6 +114,16 @@ public:
                             std::vector<Match>& matches, float threshold = .95f, int stride = 3,
                             std::vector<float>* responses = nullptr);
 
+    // matchPoints for predictions that carry a 2x2 covariance (innovation covariance of the filter, in
+    // full-resolution pixels^2, stored as {sxx, sxy, syy}): feature i's coarsest level is searched
+    // inside the gate ellipse (p - p2d)^T S^-1 (p - p2d) <= gate instead of the fixed square of
+    // feature.cpp:134,144-146, the finer levels as in the reference.  A feature without a window
+    // (degenerate covariance, window beyond 300 pixels as in lineFeature.cpp:81-84) gets response -1.
+    // Not in the reference.
+    static void matchPointsGated(const ImagePyramid<byte>& pyramid, const std::vector<Projection>& features,
+                                 const std::vector<cv::Vec3f>& covariances, float gate, std::vector<Match>& matches,
+                                 float threshold = .95f, int stride = 3, std::vector<float>* responses = nullptr);
+
     // What LineFeature::track (lineFeature.cpp:22-96) has computed on the CPU from the cone before it
     // touches the image: the descriptor, the area rectangle on the coarsest level and the projected
     // relevant bins as circles relative to that rectangle (lineFeature.cpp:86-96).

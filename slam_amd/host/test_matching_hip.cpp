@@ -108,6 +108,37 @@ static bool test_pyramid_track_keypoints() {
     const Point2i pe = SLAM::Feature::track(pyramid, empty, 0.95f, 3, re);
     if (pe.x != -1 || pe.y != -1 || re != -1.f) return false;     // feature.cpp:112-115
 
+    // the same features with gate-ellipse windows on the coarsest level, against the oracle's windows and walk
+    std::vector<cv::Vec3f> covs;
+    for (size_t k = 0; k < feats.size(); k++) covs.push_back(cv::Vec3f(30.f + 9.f * k, 4.f * ((int)k % 5 - 2), 20.f + 3.f * k));
+    covs[3] = cv::Vec3f(1.f, 2.f, 1.f);                            // not positive definite: no window
+    std::vector<SLAM::Match> gmatches;
+    std::vector<float> gresp;
+    SLAM::matchPointsGated(pyramid, feats, covs, 9.f, gmatches, 0.95f, 3, &gresp);
+    size_t gm = 0, gfound = 0;
+    for (size_t k = 0; k < feats.size(); k++) {
+        so_ellipse e;
+        const float cov[3] = {covs[k][0], covs[k][1], covs[k][2]};
+        so_ellipse_setup(feats[k].p2d.x, feats[k].p2d.y, cov, 9.f, 1.f / subs[2], &e);
+        if (!e.valid) {
+            if (k != 3 || gresp[k] != -1.f) { printf("gated %zu: expected no window\n", k); return false; }
+            continue;
+        }
+        std::vector<uint8_t> am((size_t)e.w * e.h);
+        so_ellipse_mask(&e, am.data());
+        const int area[4] = {e.x, e.y, e.w, e.h};
+        so_track_out o;
+        so_track_ex(lev, lw, lh, subs.data(), 3, feats[k].proj.data, feats[k].projMask.data, 21, 21, feats[k].p2d.x, feats[k].p2d.y, 0.95f, 3,
+                    area, am.data(), &o);
+        if (std::memcmp(&gresp[k], &o.response, 4) != 0) { printf("gated %zu: HIP %.9g oracle %.9g\n", k, gresp[k], o.response); return false; }
+        if (o.response > 0.95f) {
+            if (gm >= gmatches.size() || gmatches[gm].iFeature != (int)k || gmatches[gm].pos.x != (float)o.x || gmatches[gm].pos.y != (float)o.y) return false;
+            gm++;
+            gfound++;
+        }
+    }
+    if (gm != gmatches.size() || gfound < 3) { printf("gated: %zu matches, %zu expected, %zu found\n", gmatches.size(), gm, gfound); return false; }
+
     SLAM slam;
     std::vector<cv::KeyPoint> kps;
     slam.getSortedKeyPoints(im, 50, kps);

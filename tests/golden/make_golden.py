@@ -107,6 +107,18 @@ def line_case(seed=synth.SEED_BASE + 22, n=8, half=20):
     return dict(frame=f1, subs=subs, jobs=jobs)
 
 
+def window_case(seed=synth.SEED_BASE + 23, n=24):
+    """Seeded uncertainty windows: predicted point, 2x2 covariance (sxx, sxy, syy), gate, level resolution."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n):
+        a, b, th = rng.uniform(2, 30), rng.uniform(1, 15), rng.uniform(0, np.pi)
+        c, s = np.cos(th), np.sin(th)
+        S = np.array([[c, -s], [s, c]]) @ np.diag([a * a, b * b]) @ np.array([[c, s], [-s, c]])
+        rows.append((rng.uniform(0, 640), rng.uniform(0, 480), S[0, 0], S[0, 1], S[1, 1], rng.choice([4.0, 9.0]), rng.choice([1.0, 0.5, 0.25])))
+    return np.array(rows, np.float32)
+
+
 def main():
     O.build()
     out = {}
@@ -157,6 +169,13 @@ def main():
         lt.append((r["x"], r["y"], r["levels_run"], int(np.float32(r["response"]).view(np.uint32))))
     out["line/mask_crc"] = np.array(mc, np.uint32)
     out["line/track"] = np.array(lt, np.int64)
+    wc = window_case()
+    wr = []
+    for row in wc:
+        o = O.ellipse_window(row[0], row[1], row[2:5], row[5], row[6])
+        wr.append(o["area"] + tuple(int(np.float32(v).view(np.uint32)) for v in o["q"] + o["centre"]) + (crc(o["mask"]),))
+    out["window/in"] = wc
+    out["window/out"] = np.array(wr, np.int64)
     f = fast_frames()[0]
     srt = O.sort_keypoints(O.fast(f, 20, True))
     out["newpoints/sel"] = O.select_new_points(srt, np.array([[100, 100], [320, 180]], np.float32), 40, 30.0, 10, 10, f.shape[1], f.shape[0])

@@ -45,6 +45,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(capi.WarpJob) == 80
     assert C.sizeof(capi.DiscJob) == 24
     assert C.sizeof(capi.LineJob) == 56
+    assert C.sizeof(capi.EllipseJob) == 48
 
 
 def test_null_context_is_rejected_without_touching_a_gpu():

@@ -1,0 +1,112 @@
+"""Uncertainty windows on the device: the gate ellipse of a 2x2 covariance as coarsest-level search window
+(slam_hip_ellipse_setup / slam_hip_ellipse_masks_d / slam_hip_track_ellipse_batch) against the oracle.  Build-defined:
+the reference has no live counterpart, so the oracle's restatement is the spec (parity unpinned)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_float(a, b):
+    return np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32) or (np.isnan(a) and np.isnan(b))
+
+
+def _random_cov(rng, smax):
+    a, b, th = float(rng.uniform(1.0, smax)), float(rng.uniform(0.5, smax / 2)), float(rng.uniform(0, np.pi))
+    c, s = np.cos(th), np.sin(th)
+    R = np.array([[c, -s], [s, c]])
+    S = R @ np.diag([a * a, b * b]) @ R.T
+    return np.array([S[0, 0], S[0, 1], S[1, 1]], np.float32)
+
+
+def test_ellipse_setup_and_masks_match_oracle(ctx, oracle):
+    rng = np.random.default_rng(77)
+    wins, exp = [], []
+    for k in range(300):
+        cov = _random_cov(rng, 40.0)
+        px, py = float(rng.uniform(-50, 700)), float(rng.uniform(-50, 500))
+        gate = float(rng.choice([1.0, 4.0, 9.0, 13.8]))
+        res = float(rng.choice([1.0, 0.5, 0.25, 1.0 / 3.0, 0.125]))
+        if k % 50 == 7:
+            cov = np.array([4.0, 5.0, 4.0], np.float32)              # not positive definite
+        if k % 50 == 9:
+            cov = cov * np.float32(1e4)                               # beyond the 300-pixel cap at res 1
+            res = 1.0
+        e = api.ellipse_setup(px, py, cov, gate, res)
+        o = oracle.ellipse_window(px, py, cov, gate, res)
+        assert bool(e.valid) == (o is not None)
+        if o is not None:
+            assert (e.x, e.y, e.w, e.h) == o["area"]
+            assert all(_same_float(a, b) for a, b in zip((e.q11, e.q12, e.q22, e.ux, e.uy), o["q"] + o["centre"]))
+        wins.append(e)
+        exp.append(o)
+    assert sum(o is None for o in exp) >= 10 and sum(o is not None for o in exp) >= 250
+    got = api.ellipse_masks(ctx, wins)
+    for g, o in zip(got, exp):
+        assert (g is None) == (o is None)
+        if o is not None:
+            assert np.array_equal(g, o["mask"])
+            assert g[int(round(o["centre"][1])), int(round(o["centre"][0]))] == 255      # the centre pixel is inside
+
+
+def test_track_with_uncertainty_windows(ctx, oracle):
+    """Feature::track with each feature's coarsest level searched under its gate ellipse, masks rasterised on the
+    device: every walk equals the oracle's walk over the oracle's window and mask."""
+    w, h, subs = 640, 480, [1.0, 2.0, 4.0]
+    rng = np.random.default_rng(synth.SEED_BASE + 91)
+    shift = (3, -2)
+    f0, f1 = synth.frame(w, h, synth.SEED_BASE + 5), synth.frame(w, h, synth.SEED_BASE + 5, shift)
+    jobs, ojobs = [], []
+    for i, (cx, cy) in enumerate(synth.feature_grid(w, h, 96, 60, rng)):
+        proj = synth.cut_template(f0, cx, cy, 21, 21)
+        mask = np.ones_like(proj)
+        mask[:int(rng.integers(0, 6)), :int(rng.integers(0, 6))] = 0
+        px = cx - shift[0] + float(rng.integers(-8, 9)) + 0.25
+        py = cy - shift[1] + float(rng.integers(-8, 9)) - 0.4
+        cov = _random_cov(rng, 16.0)
+        if i == 5:
+            cov = np.array([1.0, 2.0, 1.0], np.float32)               # no window: reported like an empty projection
+        if i == 6:
+            px, py = -30.0, 20.0                                      # window off the image
+        win = api.ellipse_setup(px, py, cov, 9.0, 1.0 / subs[-1])
+        jobs.append(dict(frame=0, proj=proj, proj_mask=mask, px=px, py=py, threshold=0.9, stride=3, window=win))
+        ojobs.append(oracle.ellipse_window(px, py, cov, 9.0, 1.0 / subs[-1]))
+    pyr = api.ImagePyramid(ctx, f1, subs)
+    try:
+        got = api.track_batch(ctx, pyr, jobs)
+    finally:
+        pyr.close()
+    levels = oracle.pyramid(f1, subs)
+    full = 0
+    for j, o, g in zip(jobs, ojobs, got):
+        assert g["status"] == 0
+        if o is None:
+            assert (g["x"], g["y"], g["response"], g["levels_run"]) == (-1, -1, -1.0, 0)
+            continue
+        r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"],
+                         coarse_area=o["area"], coarse_mask=o["mask"])
+        assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"]), (o["area"], g, r)
+        assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+        full += r["levels_run"] == 3
+    assert full >= 40
+
+
+def test_golden_windows_on_gpu(ctx):
+    """The committed window vectors (tests/golden/make_golden.py: rectangle, quadratic form, centre, mask CRC),
+    reproduced by the HIP path without the oracle in the loop."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden as MG
+    gold = np.load(os.path.join(here, "golden", "golden_r01.npz"))
+    wc = MG.window_case()
+    assert np.array_equal(wc, gold["window/in"])
+    wins = [api.ellipse_setup(r[0], r[1], r[2:5], r[5], r[6]) for r in wc]
+    masks = api.ellipse_masks(ctx, wins)
+    bits = lambda v: int(np.float32(v).view(np.uint32))
+    got = [[e.x, e.y, e.w, e.h, bits(e.q11), bits(e.q12), bits(e.q22), bits(e.ux), bits(e.uy), MG.crc(m)] for e, m in zip(wins, masks)]
+    assert got == gold["window/out"].tolist()

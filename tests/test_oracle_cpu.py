@@ -292,3 +292,44 @@ def test_disc_mask_is_the_euclidean_disc(oracle):
     m = oracle.disc_mask(20, 10, [[-3, 4, 6], [25, 5, 7]])        # clipped at both sides
     y, x = np.mgrid[0:10, 0:20]
     assert np.array_equal(m > 0, ((x + 3) ** 2 + (y - 4) ** 2 <= 36) | ((x - 25) ** 2 + (y - 5) ** 2 <= 49))
+
+
+def test_ellipse_window_contains_the_gate_ellipse(oracle):
+    """The window's rectangle holds every pixel of the gate ellipse, its mask is that ellipse (checked in double
+    away from the boundary), and degenerate covariances / oversized windows give no window."""
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        a, b, th = rng.uniform(1, 30), rng.uniform(0.5, 15), rng.uniform(0, np.pi)
+        c, s = np.cos(th), np.sin(th)
+        S = np.array([[c, -s], [s, c]]) @ np.diag([a * a, b * b]) @ np.array([[c, s], [-s, c]])
+        cov = np.array([S[0, 0], S[0, 1], S[1, 1]], np.float32)
+        px, py, gate, res = float(rng.uniform(0, 600)), float(rng.uniform(0, 400)), 9.0, float(rng.choice([1.0, 0.5, 0.25]))
+        o = oracle.ellipse_window(px, py, cov, gate, res)
+        x0, y0, w, h = o["area"]
+        assert w <= 300 and h <= 300
+        S32 = np.array([[cov[0], cov[1]], [cov[1], cov[2]]], np.float64)
+        Q = np.linalg.inv(S32 * res * res * gate)
+        yy, xx = np.mgrid[y0 - 2:y0 + h + 2, x0 - 2:x0 + w + 2]
+        dx, dy = xx - px * res, yy - py * res
+        t = Q[0, 0] * dx * dx + 2 * Q[0, 1] * dx * dy + Q[1, 1] * dy * dy
+        inside = t <= 1 - 1e-3
+        assert not inside[:2].any() and not inside[-2:].any() and not inside[:, :2].any() and not inside[:, -2:].any()
+        m = o["mask"] > 0
+        core = t[2:-2, 2:-2]
+        assert m[core <= 1 - 1e-3].all() and not m[core >= 1 + 1e-3].any()
+        assert m[:, 0].sum() + m[:, -1].sum() + m[0].sum() + m[-1].sum() <= 8      # the rectangle is tight to a pixel or two
+    assert oracle.ellipse_window(10, 10, [4, 5, 4], 9.0, 1.0) is None
+    assert oracle.ellipse_window(10, 10, [0, 0, 1], 9.0, 1.0) is None
+    assert oracle.ellipse_window(10, 10, [1e4, 0, 1], 9.0, 1.0) is None
+    assert oracle.ellipse_window(float("nan"), 10, [2, 0, 1], 9.0, 1.0) is None
+    assert oracle.ellipse_window(10, 10, [1e4, 0, 1], 9.0, 0.25) is not None
+
+
+def test_golden_windows_are_reproduced_by_the_oracle(oracle):
+    gold = np.load(GOLD)
+    wc = MG.window_case()
+    assert np.array_equal(wc, gold["window/in"])
+    bits = lambda v: int(np.float32(v).view(np.uint32))
+    for row, exp in zip(wc, gold["window/out"].tolist()):
+        o = oracle.ellipse_window(row[0], row[1], row[2:5], row[5], row[6])
+        assert list(o["area"]) + [bits(v) for v in o["q"] + o["centre"]] + [MG.crc(o["mask"])] == exp
