@@ -51,7 +51,9 @@ int slam_hip_destroy(slam_ctx* ctx);
 int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream);
 int slam_hip_synchronize(slam_ctx* ctx);
 /* LDS bytes each search job (one wavefront) may use: a multiple of 1024 in [4096, 65536], default
- * 8192.  Less LDS lets more jobs share a CU; jobs too large for it are cut into more blocks. */
+ * 12288 (12 jobs then share a CU's 160 KB, as many as the kernels' registers allow).  Less LDS never
+ * adds jobs per CU; more LDS cuts large templates into fewer chunks at the price of fewer jobs per CU.
+ * Results do not depend on it. */
 int slam_hip_set_match_lds(slam_ctx* ctx, int bytes);
 /* Text of the last error on ctx (or of the last failed slam_hip_create when ctx is NULL). */
 const char* slam_hip_last_error_string(const slam_ctx* ctx);

@@ -134,8 +134,36 @@ def main():
     res = d_res.cpu().numpy().view(np.int32).reshape(-1, 7)
     out["project_then_track_c2"] = {"ms_track_alone": ms_t, "ms_warp_plus_track": ms_wt,
                                     "tracked_all_levels": float((res[:, 5] == 3).mean())}
-    pyr.close()
     del d_desc, d_wj, d_tj, d_blob, d_res
+
+    # --- C2 at the production template size (new_image.cpp:82: 81x81): 1024 frames x 16 features, masked templates,
+    # pyramid {1,2,4}, stride 3; per feature 16 + 4 + 289 cells with 20x20, 40x40 and 81x81 templates
+    nf81, ts = 16, 81
+    pts81 = synth.feature_grid(w, h, nf81, ts + 10, rng)
+    tj = (capi.TrackJob * (nfr * nf81))()
+    parts = []
+    for k, (cx, cy) in enumerate(pts81):
+        proj = synth.cut_template(f0, cx, cy, ts, ts)
+        mask = np.ones_like(proj); mask[:6, :9] = 0; mask[-4:, -12:] = 0
+        parts += [proj.reshape(-1), mask.reshape(-1)]
+        for f in range(nfr):
+            t = tj[f * nf81 + k]
+            t.frame, t.projw, t.projh = f, ts, ts
+            t.proj_off, t.mask_off = 2 * ts * ts * k, 2 * ts * ts * k + ts * ts
+            t.px, t.py, t.threshold, t.stride = cx - 3 + 1.0, cy + 2 - 2.0, 0.9, 3
+    d_blob = torch.from_numpy(np.concatenate(parts)).to(dev)
+    d_tj = torch.from_numpy(np.frombuffer(bytes(tj), np.uint8).copy()).to(dev)
+    d_res = torch.zeros(nfr * nf81 * 28, dtype=torch.uint8, device=dev)
+    ms = timed(stream, lambda: capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_tj), nfr * nf81, P(d_blob),
+                                                                                d_blob.numel(), P(d_res))))
+    res = d_res.cpu().numpy().view(np.int32).reshape(-1, 7)
+    macs = 2.0 * (16 * 20 * 20 + 4 * 40 * 40 + 289 * 81 * 81) * nfr * nf81
+    out["c2_track_16384x81x81"] = {"ms": ms, "jobs": nfr * nf81, "all_levels": float((res[:, 5] == 3).mean()),
+                                   "found": float(((res[:, 0] == np.tile([p[0] - 3 for p in pts81], nfr)) & (res[:, 1] == np.tile([p[1] + 2 for p in pts81], nfr))).mean()),
+                                   "positions/s": 309.0 * nfr * nf81 / (ms * 1e-3), "u8_mac/s": macs / (ms * 1e-3),
+                                   "frac_of_packed_dot_peak": macs / (ms * 1e-3) / 1.4e14}
+    pyr.close()
+    del d_blob, d_tj, d_res
 
     # --- line features: 3 lines per frame (new_image.cpp:80: 3 - nLines), 81x81 descriptors, pyramid {1,2}, stride 2
     nline, half = 3, 40

@@ -33,6 +33,8 @@ def run(subs, tsize, nframes=512, steps=10, thr=0.98, stride=3, mask_cut=True):
     pyr = api.ImagePyramid(ctx, None, subs, device_ptr=d_frames.data_ptr(), pitch=bench.W, frame_stride=bench.W * bench.H,
                            shape=(nframes, bench.H, bench.W))
     L = capi.lib()
+    if os.environ.get("SLAM_PROBE_LDS"):               # LDS bytes per job (occupancy against chunking)
+        capi.check(ctx.handle, L.slam_hip_set_match_lds(ctx.handle, int(os.environ["SLAM_PROBE_LDS"])))
 
     def go():
         capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, C.c_void_p(d_jobs.data_ptr()), njobs,
@@ -51,6 +53,9 @@ def run(subs, tsize, nframes=512, steps=10, thr=0.98, stride=3, mask_cut=True):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "size":     # one template size, never stops early
+        run([1.0, 2.0, 4.0], int(sys.argv[2]), nframes=256 if int(sys.argv[2]) > 40 else 1024, steps=4, thr=-10.0)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "one":      # one configuration that never stops early (for counter passes)
         run([1.0, 2.0, 4.0], 21, nframes=1024, steps=2, thr=-10.0)
         sys.exit(0)

@@ -169,6 +169,33 @@ def test_match_edge_cases(ctx, oracle):
     _check_match(ctx, oracle, im, patch, np.zeros_like(patch), (3, 3, 8, 8), None, 1)
 
 
+def test_match_maximum_sizes(ctx, oracle):
+    """The sizes at the far end of the reference's use: templates of more than 66051 pixels (their integer sums
+    leave 32 bits: 64-bit accumulators), a template wider than the tiled core takes (direct evaluation), the
+    500x500 bound of a projected template (feature.cpp:84), the 300x300 area cap of lineFeature.cpp:27,81, and
+    saturated images (every product 255*255) that drive the sums to their maxima."""
+    rng = np.random.default_rng(99)
+    im = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    big = synth.cut_template(im, 320, 240, 300, 260)                         # 78 000 pixels: 64-bit sums
+    bm = (rng.random(big.shape) < 0.8).astype(np.uint8)
+    ref, got = _check_match(ctx, oracle, im, big, bm, (314, 236, 12, 9), None, 1)
+    assert (got["x"], got["y"]) == (320, 240) and got["response"] > 0.999
+    _check_match(ctx, oracle, im, big, None, (310, 232, 20, 16), None, 3)
+    _check_match(ctx, oracle, im, big, bm, (-20, 400, 60, 90), None, 7)       # mostly over the border
+    wide = synth.cut_template(im, 320, 100, 520, 31)                         # wider than 512: direct evaluation
+    _check_match(ctx, oracle, im, wide, (rng.random(wide.shape) < 0.5).astype(np.uint8), (316, 97, 9, 7), None, 1)
+    p500 = synth.cut_template(rng.integers(0, 256, (520, 700), dtype=np.uint8), 350, 260, 500, 500)
+    im2 = rng.integers(0, 256, (520, 700), dtype=np.uint8)
+    _check_match(ctx, oracle, im2, p500, np.ones_like(p500), (348, 258, 5, 5), None, 2)
+    small = synth.cut_template(im, 200, 200, 9, 9)
+    am = (rng.random((300, 300)) < 0.5).astype(np.uint8) * 255
+    ref, got = _check_match(ctx, oracle, im, small, None, (60, 50, 300, 300), am, 2)
+    _check_match(ctx, oracle, im, small, np.ones_like(small), (60, 50, 300, 300), am, 2, exact=True)
+    sat = np.full((300, 400), 255, np.uint8)                                 # the largest sums a window can reach
+    _check_match(ctx, oracle, sat, np.full((270, 260), 255, np.uint8), None, (128, 133, 6, 5), None, 1)
+    _check_match(ctx, oracle, sat, np.full((270, 260), 255, np.uint8), np.ones((270, 260), np.uint8), (120, 130, 30, 12), None, 4)
+
+
 def test_match_rejects_bad_mask_values(ctx):
     im = np.zeros((20, 20), np.uint8)
     patch = np.ones((5, 5), np.uint8)
@@ -222,7 +249,8 @@ def _c2_like_jobs(rng, w, h, nfeat, tsize, frame0, shift):
 
 
 @pytest.mark.parametrize("w,h,subs,nfeat,tsize,min_found", [(640, 480, [1, 2, 4], 64, 21, 40), (640, 480, [1, 3], 24, 27, 14),
-                                                            (320, 240, [1], 16, 11, 14), (640, 360, [1, 2, 4, 8], 32, 31, 5)])
+                                                            (320, 240, [1], 16, 11, 14), (640, 360, [1, 2, 4, 8], 32, 31, 5),
+                                                            (640, 480, [1, 3], 12, 81, 6)])     # the reference's live setting: matching.cpp:247-250, new_image.cpp:82
 def test_track_matches_oracle(ctx, oracle, w, h, subs, nfeat, tsize, min_found):
     rng = np.random.default_rng(w + nfeat)
     shift = (int(rng.integers(-6, 7)), int(rng.integers(-6, 7)))
@@ -253,6 +281,37 @@ def test_track_matches_oracle(ctx, oracle, w, h, subs, nfeat, tsize, min_found):
         assert nfound >= min_found      # sanity: the synthetic sequence is actually tracked
     finally:
         pyr.close()
+
+
+@pytest.mark.parametrize("lds", [4096, 8192, 32768])
+def test_results_do_not_depend_on_the_lds_budget(oracle, lds):
+    """The LDS a job may use only changes how its work is cut into blocks and chunks (slam_hip_set_match_lds):
+    walks, single searches with score maps and line-style searches give the oracle's results at every budget."""
+    rng = np.random.default_rng(lds)
+    w, h, subs, shift = 640, 480, [1, 2, 4], (4, -3)
+    f0, f1 = synth.frame(w, h, 12), synth.frame(w, h, 12, shift)
+    with api.Context(0) as c:
+        api.capi.check(c.handle, api.capi.lib().slam_hip_set_match_lds(c.handle, lds))
+        jobs = _c2_like_jobs(rng, w, h, 24, 21, f0, shift) + _c2_like_jobs(rng, w, h, 4, 81, f0, shift)
+        pyr = api.ImagePyramid(c, f1, subs)
+        try:
+            got = api.track_batch(c, pyr, jobs)
+        finally:
+            pyr.close()
+        levels = oracle.pyramid(f1, subs)
+        for j, g in zip(jobs, got):
+            r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+            assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"])
+            assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+        im = rng.integers(0, 256, (120, 160), dtype=np.uint8)
+        for (pw, ph, area, stride, masked) in [(9, 7, (-4, -3, 70, 50), 1, True), (33, 29, (20, 10, 90, 60), 2, True),
+                                               (61, 47, (40, 30, 40, 30), 1, False), (130, 90, (60, 40, 12, 9), 1, True),
+                                               (5, 5, (0, 0, 160, 120), 3, False)]:
+            patch = rng.integers(0, 256, (ph, pw), dtype=np.uint8)
+            pm = (rng.random((ph, pw)) < 0.7).astype(np.uint8) if masked else None
+            am = (rng.random((area[3], area[2])) < 0.6).astype(np.uint8)
+            _check_match(c, oracle, im, patch, pm, area, am, stride)
+            _check_match(c, oracle, im, patch, pm, area, None, stride)
 
 
 def _kp_set(a):
