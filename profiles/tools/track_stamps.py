@@ -20,6 +20,10 @@ def main():
     import torch
     from slam_amd import api, capi
     nframes = 512
+    if len(sys.argv) > 1:                               # template size (default: the bench's)
+        bench.TSIZE = int(sys.argv[1])
+        bench.THRESHOLD = -10.0                         # never stops early
+        nframes = 128 if bench.TSIZE > 40 else 512
     rng = np.random.default_rng(5)
     frames, jobs, blob, truth = bench.build_workload(nframes, 77, rng)
     dev = torch.device("cuda", 0)

@@ -241,15 +241,30 @@ __device__ __forceinline__ void resize_tap(int d, double scale, int ssize, bool 
     ofs = s;
 }
 
-__device__ __forceinline__ int resize_px(const uint8_t* S, int sw, int sh, int sx, int a0, int a1, int sy, int b0, int b1, bool binarize) {
+// All products fit 24-bit operands (pixels < 2^8, weights <= 2^11, row sums >> 4 < 2^15, template sides < 2^23), so
+// the full-rate 24-bit multiplier gives the same integers as 32-bit arithmetic.
+struct ResizeSrc { int p00, p01, p10, p11; };
+
+// the four source pixels of one resized pixel (rows clamped when used, second column clamped at the edge)
+__device__ __forceinline__ ResizeSrc resize_fetch(const uint8_t* S, int sw, int sh, int sx, int sy) {
     const int r0 = min(max(sy, 0), sh - 1), r1 = min(max(sy + 1, 0), sh - 1);
     const int sx1 = min(sx + 1, sw - 1);
-    int p00 = S[(long long)r0 * sw + sx], p01 = S[(long long)r0 * sw + sx1];
-    int p10 = S[(long long)r1 * sw + sx], p11 = S[(long long)r1 * sw + sx1];
-    if (binarize) { p00 = p00 != 0; p01 = p01 != 0; p10 = p10 != 0; p11 = p11 != 0; }
-    const int h0 = p00 * a0 + p01 * a1;
-    const int h1 = p10 * a0 + p11 * a1;
-    return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+    const unsigned o0 = __umul24((unsigned)r0, (unsigned)sw), o1 = __umul24((unsigned)r1, (unsigned)sw);
+    ResizeSrc r;
+    r.p00 = S[o0 + (unsigned)sx]; r.p01 = S[o0 + (unsigned)sx1];
+    r.p10 = S[o1 + (unsigned)sx]; r.p11 = S[o1 + (unsigned)sx1];
+    return r;
+}
+
+__device__ __forceinline__ int resize_blend(ResizeSrc r, int a0, int a1, int b0, int b1, bool binarize) {
+    if (binarize) { r.p00 = r.p00 != 0; r.p01 = r.p01 != 0; r.p10 = r.p10 != 0; r.p11 = r.p11 != 0; }
+    const int h0 = __mul24(r.p00, a0) + __mul24(r.p01, a1);
+    const int h1 = __mul24(r.p10, a0) + __mul24(r.p11, a1);
+    return (((__mul24(b0, h0 >> 4) >> 16) + (__mul24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xff;
+}
+
+__device__ __forceinline__ int resize_px(const uint8_t* S, int sw, int sh, int sx, int a0, int a1, int sy, int b0, int b1, bool binarize) {
+    return resize_blend(resize_fetch(S, sw, sh, sx, sy), a0, a1, b0, b1, binarize);
 }
 
 // patch value and mask bit (0/1) of template pixel (row u, column v)

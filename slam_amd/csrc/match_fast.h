@@ -158,7 +158,7 @@ __device__ __forceinline__ Walk2D make_walk(int width, int rows) {
 // else uses until this returns) holds the tap tables of the resize.  Ends with the staged rows NOT yet visible
 // to other lanes: the caller synchronises.
 __device__ __forceinline__ void stage_template(const Geo& g, const Tmpl& t, lds_u64* tmpl, lds_u64* taps_region, int taps_bytes,
-                                               int u0, int ur, int G, unsigned long long& sp_part) {
+                                               int u0, int ur, int G, unsigned long long& sp_part STAMP_ARG) {
     const int lane = threadIdx.x;
     {
     // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
@@ -175,23 +175,46 @@ __device__ __forceinline__ void stage_template(const Geo& g, const Tmpl& t, lds_
             taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)o;
         }
         __syncthreads();
+        STAMP(44);
         lds_u8* tb = reinterpret_cast<lds_u8*>(tmpl);
         const int wpx = G * 4;
         const float rw = __builtin_amdgcn_rcpf((float)wpx);
-        for (int i = lane; i < ur * wpx; i += SLAM_WG) {
-            const int u = (int)(((float)i + 0.5f) * rw), v = i - u * wpx;
-            unsigned p = 0, m = 0;
-            if (v < g.pw) {
-                const unsigned long long tx = taps[v], ty = taps[wpx + u];
-                const int sx = (int)(unsigned)tx, sy = (int)(unsigned)ty;
-                const int a0 = (short)(tx >> 32), a1 = (short)(tx >> 48), b0 = (short)(ty >> 32), b1 = (short)(ty >> 48);
-                m = t.mask ? (unsigned)(resize_px(t.mask, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, true) != 0) : 1u;
-                p = (unsigned)resize_px(t.patch, t.srcw, t.srch, sx, a0, a1, sy, b0, b1, false) * m;
+        // four pixels per lane and pass: their 32 source bytes are all requested before the first blend, so a
+        // pass costs one memory round trip (without a mask the patch stands in for it and the result is ignored)
+        constexpr int NB = 4;
+        const int n = ur * wpx;
+        const uint8_t* msrc = t.mask ? t.mask : t.patch;
+        const unsigned nomask = t.mask ? 0u : 1u;
+        for (int i0 = lane; i0 < n; i0 += NB * SLAM_WG) {
+            ResizeSrc sp[NB], sm[NB];
+            unsigned long long tx[NB], ty[NB];
+            int e[NB];
+            bool pad[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int i = min(i0 + q * SLAM_WG, n - 1);
+                const int u = (int)(((float)i + 0.5f) * rw), v = i - __mul24(u, wpx);
+                tx[q] = taps[min(v, g.pw - 1)]; ty[q] = taps[wpx + u];
+                pad[q] = v >= g.pw;                                  // padding columns of the last group
+                e[q] = (__mul24(u, G) + (v >> 2)) * 8 + (v & 3);     // byte of the {P0, mask} entry
             }
-            sp_part += p * p;
-            const int e = (u * G + (v >> 2)) * 8 + (v & 3);        // byte of the {P0, mask} entry
-            tb[e] = (unsigned char)p;
-            tb[e + 4] = m ? 0xFF : 0x00;
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                sm[q] = resize_fetch(msrc, t.srcw, t.srch, (int)(unsigned)tx[q], (int)(unsigned)ty[q]);
+                sp[q] = resize_fetch(t.patch, t.srcw, t.srch, (int)(unsigned)tx[q], (int)(unsigned)ty[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int a0 = (short)(tx[q] >> 32), a1 = (short)(tx[q] >> 48), b0 = (short)(ty[q] >> 32), b1 = (short)(ty[q] >> 48);
+                unsigned m = (unsigned)(resize_blend(sm[q], a0, a1, b0, b1, true) != 0) | nomask;
+                unsigned p = (unsigned)resize_blend(sp[q], a0, a1, b0, b1, false) * m;
+                if (pad[q]) { p = 0; m = 0; }
+                if (i0 + q * SLAM_WG < n) {
+                    sp_part += p * p;
+                    tb[e[q]] = (unsigned char)p;
+                    tb[e[q] + 4] = m ? 0xFF : 0x00;
+                }
+            }
         }
         __syncthreads();                               // the taps are dead before the tile is staged over them
     } else {
@@ -263,7 +286,7 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         const int ur = min(UR, g.ph - u0);
         __syncthreads();                                   // previous chunk's readers are done
         STAMP(10);
-        stage_template(g, t, tmpl, reinterpret_cast<lds_u64*>(tile), lp.tile_bytes, u0, ur, G, sp_part);
+        stage_template(g, t, tmpl, reinterpret_cast<lds_u64*>(tile), lp.tile_bytes, u0, ur, G, sp_part STAMP_PASS);
         STAMP(11);
         // ---- stage the image tile (and its validity) --------------------------------------------
         {
@@ -544,7 +567,7 @@ __device__ __forceinline__ CoreOut mini_level(const Geo& g, const Tmpl& t, lds_u
     lds_u32* tile = reinterpret_cast<lds_u32*>(lds + g.ph * G * 8);
     unsigned long long sp_part = 0;
     __syncthreads();                                   // earlier readers of this LDS are done
-    stage_template(g, t, tmpl, reinterpret_cast<lds_u64*>(tile), t.resized ? (G * 4 + g.ph) * 8 : 0, 0, g.ph, G, sp_part);
+    stage_template(g, t, tmpl, reinterpret_cast<lds_u64*>(tile), t.resized ? (G * 4 + g.ph) * 8 : 0, 0, g.ph, G, sp_part STAMP_PASS);
     STAMP(40);
     {   // image tile: rows y0 .. y0 + ah + ph - 2, dword columns from (x0 & ~3); all inside the image
         const uint8_t* base = g.im + (long long)g.y0 * g.ipitch + (g.x0 - mp.o);
