@@ -31,6 +31,7 @@ STRIDE = 3
 THRESHOLD = 0.98
 SEQ_LEN = 32
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+HBM_COPY_GBS = 6290.0          # what a plain device-to-device copy reaches on this part (secondary denominator)
 # Packed u8 dot (v_dot4_u32_u8): measured on gfx950 at ~4.5 cycles per wave64 instruction per SIMD
 # (profiles/tools/valu_rate.hip), i.e. half the rate of a plain 32-bit VALU op:
 # CUs x SIMDs x 64 lanes x 4 MAC / 4.5 clk x 2.4 GHz.
@@ -363,13 +364,14 @@ def main():
                        "frames_per_s": nframes * world * args.steps / elapsed, "tracked_fraction": tracked, "h2d_in_step": bool(args.with_h2d),
                        "parallelism": "frames sharded over %d GPU(s), no collective on the data path" % world},
             "roofline": {"bound": "hbm", "kernel": "track_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": ach / HBM_COPY_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                          "u8_mac_per_s": macs / (kern_ms * 1e-3), "frac_of_packed_dot_peak": macs / (kern_ms * 1e-3) / DOT4_PEAK_MACS},
             "cpu_baseline": cpu,
             # the other two kernels BASELINE.json's metric names, measured in the same run (outside the timed steps)
             "pyramid": {"kernel": "pyr_build_kernel", "ms": pyr_ms, "achieved": pyr_bytes / (pyr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_of_measured_copy_rate": pyr_bytes / (pyr_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
                         "algorithmic_bytes_per_launch": pyr_bytes},
             "fast": fast,
         }

@@ -314,6 +314,36 @@ def test_results_do_not_depend_on_the_lds_budget(oracle, lds):
             _check_match(c, oracle, im, patch, pm, area, None, stride)
 
 
+def test_direct_evaluation_path_gives_the_same_results(oracle, monkeypatch):
+    """SLAM_HIP_FORCE_DIRECT=1 (read when a context is created) sends every search through the one-lane-per-cell
+    evaluation that templates too wide for the tiled core use: a second implementation on the device, which must
+    agree with the oracle - and therefore with the tiled core - on walks and on full score maps."""
+    monkeypatch.setenv("SLAM_HIP_FORCE_DIRECT", "1")
+    rng = np.random.default_rng(31)
+    w, h, subs, shift = 320, 240, [1, 2, 4], (-2, 5)
+    f0, f1 = synth.frame(w, h, 13), synth.frame(w, h, 13, shift)
+    with api.Context(0) as c:
+        jobs = _c2_like_jobs(rng, w, h, 12, 21, f0, shift)
+        pyr = api.ImagePyramid(c, f1, subs)
+        try:
+            got = api.track_batch(c, pyr, jobs)
+        finally:
+            pyr.close()
+        levels = oracle.pyramid(f1, subs)
+        for j, g in zip(jobs, got):
+            r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+            assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"])
+            assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+        im = rng.integers(0, 256, (90, 120), dtype=np.uint8)
+        for (pw, ph, area, stride, masked, exact) in [(9, 7, (-4, -3, 50, 40), 1, True, False), (15, 11, (20, 10, 60, 40), 3, True, False),
+                                                      (21, 17, (30, 20, 30, 25), 1, False, True), (5, 5, (100, 70, 30, 30), 2, False, False)]:
+            patch = rng.integers(0, 256, (ph, pw), dtype=np.uint8)
+            pm = (rng.random((ph, pw)) < 0.7).astype(np.uint8) if masked else None
+            am = (rng.random((area[3], area[2])) < 0.6).astype(np.uint8)
+            _check_match(c, oracle, im, patch, pm, area, am, stride, exact)
+            _check_match(c, oracle, im, patch, pm, area, None, stride)
+
+
 def _kp_set(a):
     return [tuple(r) for r in np.asarray(a).tolist()]
 
