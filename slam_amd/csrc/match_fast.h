@@ -128,6 +128,19 @@ __device__ __forceinline__ float cell_from_acc(const Geo& g, const lds_u8* acc, 
     return __fdiv_rn((float)(double)CC, __fmul_rn((float)si, p2));       // matching.cpp:70-72
 }
 
+// Single-precision estimate of cell_from_acc for an enumerated cell of a block without border cells and with 32-bit
+// sums: -1 for a cell the reference never visits, -FLT_MAX where the exact score is NaN (it never wins), else
+// CC / (sqrt(SI) * |P0|) up to a relative error below 1e-6 (matchTemplate's value is the same quotient, capped at 1).
+__device__ __forceinline__ float cell_estimate(const Geo& g, const lds_u8* acc, const BlockArgs& ba, int x, int y, float rn) {
+    const bool am = !g.amask || g.amask[(long long)y * g.ampitch + x] != 0;
+    if (!am && (g.masked || g.exact)) return -1.f;
+    const int c = ((y - ba.yb) * ba.strips) * FAST_J + (x - ba.xb);
+    const unsigned CC = reinterpret_cast<const lds_u32*>(acc)[c * 2], SI = reinterpret_cast<const lds_u32*>(acc)[c * 2 + 1];
+    if (SI == 0u) return g.masked ? -FLT_MAX : 0.f;
+    const float e = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+    return g.masked ? e : fminf(e, 1.f);
+}
+
 // Lane -> (row, column) walk over a rows x width rectangle without per-element divisions:
 // when width <= 64 a lane keeps its column and steps rows by 64/width, else rows are done one at a
 // time with the lanes striding over the columns.
@@ -393,9 +406,27 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
         }
         if (nx > 0 && ny > 0) {
             const float rnx = __builtin_amdgcn_rcpf((float)nx);
+            // Only the maximum is wanted here, and the exact formulas (double square root, IEEE division) cost far
+            // more than the sums' two loads: a first pass estimates every score in single precision (relative
+            // error below 1e-6), and only cells whose estimate comes within 1e-5 of the largest one - the only
+            // ones that can hold the maximum or tie with it - are scored exactly.
+            const bool prune = decided && !scores && !big && nx * ny > SLAM_WG && nm.tn > 0.0;
+            const float rn = __builtin_amdgcn_rcpf(nm.p2f);
+            float keep_from = -FLT_MAX;
+            if (prune) {
+                float m = -FLT_MAX;
+                for (int i = lane; i < nx * ny; i += SLAM_WG) {
+                    const int r = (int)(((float)i + 0.5f) * rnx), c = i - r * nx;
+                    m = fmaxf(m, cell_estimate(g, acc, ba, cx0 + c * step, cy0 + r * step, rn));
+                }
+#pragma unroll
+                for (int d = 1; d < SLAM_WG; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+                keep_from = m - 1e-5f * fmaxf(m, 1.f);
+            }
             for (int i = lane; i < nx * ny; i += SLAM_WG) {
                 const int r = (int)(((float)i + 0.5f) * rnx), c = i - r * nx;
                 const int x = cx0 + c * step, y = cy0 + r * step;
+                if (prune && !(cell_estimate(g, acc, ba, x, y, rn) >= keep_from)) continue;
                 const float sc = cell_from_acc(g, acc, ba, big, x, y, nm, decided);
                 const int idx = y * g.aw + x;
                 if (scores) scores[idx] = sc;
