@@ -39,6 +39,12 @@ def counter_by_kernel(path, counter):
 
 
 def main():
+    if sys.argv[1] == "--side":        # kernel table of a `rocprofv3 --kernel-trace --stats -- python3 profiles/tools/side_probes.py` run
+        text, _ = kernel_stats(sqlite3.connect(sys.argv[2]))
+        with open(os.path.join(ROOT, "profiles", sys.argv[3] + "_side_kernel_stats.txt"), "w") as fh:
+            fh.write("rocprofv3 --kernel-trace --stats -- python3 profiles/tools/side_probes.py   (1 GPU)\n" + text + "\n")
+        print(text)
+        return
     src, tag = sys.argv[1], sys.argv[2]
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     prof = os.path.join(ROOT, "profiles")
