@@ -112,7 +112,7 @@ typedef struct slam_match_job {
 } slam_match_job;
 
 typedef struct slam_match_result {
-    int32_t x, y;       /* returned Point2i (matching.cpp:222-227); (0,0) when the area misses the image */
+    int32_t x, y;       /* returned Point2i (matching.cpp:222-227); (0,0) when the area misses the image or is empty */
     float   response;   /* matching.cpp:224; -1 when the area misses the image (matching.cpp:26-30) */
     float   dx, dy;     /* sub-pixel offset of the peak in [-0.5, 0.5]; not in the reference */
     int32_t status;     /* 0, or SLAM_HIP_EINVAL when the job's fields are unusable */
