@@ -56,6 +56,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "size":     # one template size, never stops early
         run([1.0, 2.0, 4.0], int(sys.argv[2]), nframes=256 if int(sys.argv[2]) > 40 else 1024, steps=4, thr=-10.0)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "coarsest":  # every walk stops after the coarsest level
+        run([1.0, 2.0, 4.0], 21, nframes=1024, steps=2, thr=10.0)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "one":      # one configuration that never stops early (for counter passes)
         run([1.0, 2.0, 4.0], 21, nframes=1024, steps=2, thr=-10.0)
         sys.exit(0)

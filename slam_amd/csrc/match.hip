@@ -10,9 +10,15 @@
 
 using namespace slamdev;
 
-// minimum wavefronts per SIMD the register allocation must allow (caps VGPRs at 512 / this)
+// Minimum wavefronts per SIMD the register allocation must allow (caps VGPRs at 512 / this).  Four waves (128
+// VGPRs, a few spilled to scratch) beat three (168, none spilled) wherever a launch has more jobs than the chip has
+// wave slots: C2 walks by 3-5 %, 81x81 walks by 8-16 %.  Line walks come three to a frame (new_image.cpp:80): a
+// batch rarely fills the slots, so that kernel keeps the spill-free allocation.
 #ifndef SLAM_MIN_WAVES
-#define SLAM_MIN_WAVES 3
+#define SLAM_MIN_WAVES 4
+#endif
+#ifndef SLAM_MIN_WAVES_LINE
+#define SLAM_MIN_WAVES_LINE 3
 #endif
 
 namespace {
@@ -161,6 +167,18 @@ __device__ __forceinline__ int round_f2i(float f) {
 }
 
 // value of lane `i` (wave-uniform index)
+// per-level constants of a point walk, one LDS entry per pyramid level
+struct TrackLevel { float sub, rad; int lw, lh, tw, th, rs, pad; long long lp, ls, ld; double scx, scy; };
+
+// a value every lane holds alike, moved to scalar registers
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ long long uni_i64(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ int lane_i32(int v, int i) { return __builtin_amdgcn_readlane(v, i); }
 __device__ __forceinline__ float lane_f32(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
 __device__ __forceinline__ long long lane_i64(long long v, int i) {
@@ -266,37 +284,41 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
     STAMP_DECL;
     STAMP(1);
     // Per-level constants do not depend on the walk's results: lane l computes those of level l once
-    // (template size and cv::resize scales, search radius, window size); the level loop then reads
-    // lane i.  Lanes beyond the last level repeat level 0.
-    const int L = tid < pyr.nlev ? tid : 0;
-    float sub_l = 1.f, subn_l = 1.f;
-    int lw_l = 0, lh_l = 0; long long lp_l = 0, ls_l = 0; const uint8_t* ld_l = nullptr;
+    // (template size and cv::resize scales, search radius, window size) and parks them in LDS; the level
+    // loop reads entry i back into scalar registers.
+    __shared__ TrackLevel lc[SLAM_HIP_MAX_LEVELS];
+    if (tid < pyr.nlev) {
+        TrackLevel c;
+        float subn = 1.f;
 #pragma unroll
-    for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++) {
-        if (l == L) { sub_l = pyr.lev[l].sub; lw_l = pyr.lev[l].w; lh_l = pyr.lev[l].h; lp_l = pyr.lev[l].pitch; ls_l = pyr.lev[l].frame_stride; ld_l = pyr.lev[l].data; }
-        if (l == L + 1) subn_l = pyr.lev[l].sub;
-    }
-    STAMP(8);
-    int tw_l = job.projw, th_l = job.projh;      // feature.cpp:126-128
-    double scx_l = 1.0, scy_l = 1.0;
-    if (sub_l != 1.f) {                          // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
-        tw_l = (int)__fdiv_rn((float)job.projw, sub_l);
-        th_l = (int)__fdiv_rn((float)job.projh, sub_l);
-        if (tw_l > 0 && th_l > 0) {
-            scx_l = resize_scale(job.projw, tw_l);
-            scy_l = resize_scale(job.projh, th_l);
+        for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++) {
+            if (l == tid) { c.sub = pyr.lev[l].sub; c.lw = pyr.lev[l].w; c.lh = pyr.lev[l].h; c.lp = pyr.lev[l].pitch; c.ls = pyr.lev[l].frame_stride; c.ld = reinterpret_cast<long long>(pyr.lev[l].data); }
+            if (l == tid + 1) subn = pyr.lev[l].sub;
         }
+        STAMP(8);
+        c.tw = job.projw; c.th = job.projh;      // feature.cpp:126-128
+        c.scx = 1.0; c.scy = 1.0;
+        if (c.sub != 1.f) {                      // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
+            c.tw = (int)__fdiv_rn((float)job.projw, c.sub);
+            c.th = (int)__fdiv_rn((float)job.projh, c.sub);
+            if (c.tw > 0 && c.th > 0) {
+                c.scx = resize_scale(job.projw, c.tw);
+                c.scy = resize_scale(job.projh, c.th);
+            }
+        }
+        STAMP(7);
+        if (tid == pyr.nlev - 1) {
+            c.rad = __fdiv_rn(20.f, c.sub);      // feature.cpp:119,134
+        } else {                                 // feature.cpp:136-138: double expression stored to float
+            c.rad = (float)__ddiv_rn(__dmul_rn(1.3, (double)subn), (double)c.sub);
+            if (tid == 0) c.rad = __fmul_rn(c.rad, (float)job.stride);
+        }
+        c.rs = round_f2i(__fadd_rn(__fmul_rn(2.f, c.rad), 1.f));   // feature.cpp:146
+        c.pad = 0;
+        lc[tid] = c;
     }
-    STAMP(7);
-    float rad_l;
-    if (L == pyr.nlev - 1) {
-        rad_l = __fdiv_rn(20.f, sub_l);          // feature.cpp:119,134
-    } else {                                     // feature.cpp:136-138: double expression stored to float
-        rad_l = (float)__ddiv_rn(__dmul_rn(1.3, (double)subn_l), (double)sub_l);
-        if (L == 0) rad_l = __fmul_rn(rad_l, (float)job.stride);
-    }
-    const int rs_l = round_f2i(__fadd_rn(__fmul_rn(2.f, rad_l), 1.f));   // feature.cpp:146
     const double stop_below = __dmul_rn(0.67, (double)job.threshold);           // feature.cpp:151
+    __syncthreads();
     STAMP(6);
 
     float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
@@ -304,14 +326,16 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
     int levels_run = 0;
     bool empty_level = false;
     for (int i = pyr.nlev - 1; i >= 0; --i) {
-        const float sub = lane_f32(sub_l, i), searchRad = lane_f32(rad_l, i);
-        const int lw = lane_i32(lw_l, i), lh = lane_i32(lh_l, i), rs = lane_i32(rs_l, i);
-        const long long lp = lane_i64(lp_l, i), ls = lane_i64(ls_l, i);
-        const uint8_t* ld = reinterpret_cast<const uint8_t*>(lane_i64(reinterpret_cast<long long>(ld_l), i));
-        t.tw = lane_i32(tw_l, i); t.th = lane_i32(th_l, i);
+        const TrackLevel c = lc[i];
+        const float sub = uni_f32(c.sub), searchRad = uni_f32(c.rad);
+        const int lw = uni_i32(c.lw), lh = uni_i32(c.lh), rs = uni_i32(c.rs);
+        const long long lp = uni_i64(c.lp), ls = uni_i64(c.ls);
+        const uint8_t* ld = reinterpret_cast<const uint8_t*>(uni_i64(c.ld));
+        t.tw = uni_i32(c.tw); t.th = uni_i32(c.th);
         t.resized = sub != 1.f;
         if (t.tw <= 0 || t.th <= 0) { empty_level = true; break; }
-        t.scale_x = lane_f64(scx_l, i); t.scale_y = lane_f64(scy_l, i);
+        t.scale_x = __longlong_as_double(uni_i64(__double_as_longlong(c.scx)));
+        t.scale_y = __longlong_as_double(uni_i64(__double_as_longlong(c.scy)));
         // feature.cpp:144-146
         int rx = __builtin_amdgcn_readfirstlane(round_f2i(__fsub_rn(__fdiv_rn(tx, sub), searchRad)));
         int ry = __builtin_amdgcn_readfirstlane(round_f2i(__fsub_rn(__fdiv_rn(ty, sub), searchRad)));
@@ -352,7 +376,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
 // descriptor resized to the coarsest level and searched without a patch mask inside the area mask
 // (lineFeature.cpp:124-127), then, while the response stays above 0.67*threshold, each finer level in
 // a (2*searchRad+1)^2 window around the previous result (lineFeature.cpp:144-160).
-__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void line_track_kernel(slam_pyr_dev pyr, const slam_line_job* __restrict__ jobs,
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE) void line_track_kernel(slam_pyr_dev pyr, const slam_line_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
                                                         slam_track_result* __restrict__ out, int force_direct, int lds_total) {
@@ -624,9 +648,9 @@ extern "C" int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, c
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(line_track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
+    hipLaunchKernelGGL(line_track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->line_lds_bytes,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                       ctx->force_direct, ctx->match_lds_bytes);
+                       ctx->force_direct, ctx->line_lds_bytes);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }

@@ -199,33 +199,35 @@ __device__ __forceinline__ void stage_template(const Geo& g, const Tmpl& t, lds_
         const uint8_t* msrc = t.mask ? t.mask : t.patch;
         const unsigned nomask = t.mask ? 0u : 1u;
         for (int i0 = lane; i0 < n; i0 += NB * SLAM_WG) {
+            const int nq = min(NB, (n - (i0 - lane) + SLAM_WG - 1) >> 6);   // pixels per lane in this pass (wave-uniform)
             ResizeSrc sp[NB], sm[NB];
             unsigned long long tx[NB], ty[NB];
             int e[NB];
             bool pad[NB];
 #pragma unroll
             for (int q = 0; q < NB; q++) {
-                const int i = min(i0 + q * SLAM_WG, n - 1);
-                const int u = (int)(((float)i + 0.5f) * rw), v = i - __mul24(u, wpx);
-                tx[q] = taps[min(v, g.pw - 1)]; ty[q] = taps[wpx + u];
-                pad[q] = v >= g.pw;                                  // padding columns of the last group
-                e[q] = (__mul24(u, G) + (v >> 2)) * 8 + (v & 3);     // byte of the {P0, mask} entry
+                if (q < nq) {
+                    const int i = min(i0 + q * SLAM_WG, n - 1);
+                    const int u = (int)(((float)i + 0.5f) * rw), v = i - __mul24(u, wpx);
+                    tx[q] = taps[min(v, g.pw - 1)]; ty[q] = taps[wpx + u];
+                    pad[q] = v >= g.pw;                                  // padding columns of the last group
+                    e[q] = (__mul24(u, G) + (v >> 2)) * 8 + (v & 3);     // byte of the {P0, mask} entry
+                    sm[q] = resize_fetch(msrc, t.srcw, t.srch, (int)(unsigned)tx[q], (int)(unsigned)ty[q]);
+                    sp[q] = resize_fetch(t.patch, t.srcw, t.srch, (int)(unsigned)tx[q], (int)(unsigned)ty[q]);
+                }
             }
 #pragma unroll
             for (int q = 0; q < NB; q++) {
-                sm[q] = resize_fetch(msrc, t.srcw, t.srch, (int)(unsigned)tx[q], (int)(unsigned)ty[q]);
-                sp[q] = resize_fetch(t.patch, t.srcw, t.srch, (int)(unsigned)tx[q], (int)(unsigned)ty[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                const int a0 = (short)(tx[q] >> 32), a1 = (short)(tx[q] >> 48), b0 = (short)(ty[q] >> 32), b1 = (short)(ty[q] >> 48);
-                unsigned m = (unsigned)(resize_blend(sm[q], a0, a1, b0, b1, true) != 0) | nomask;
-                unsigned p = (unsigned)resize_blend(sp[q], a0, a1, b0, b1, false) * m;
-                if (pad[q]) { p = 0; m = 0; }
-                if (i0 + q * SLAM_WG < n) {
-                    sp_part += p * p;
-                    tb[e[q]] = (unsigned char)p;
-                    tb[e[q] + 4] = m ? 0xFF : 0x00;
+                if (q < nq) {
+                    const int a0 = (short)(tx[q] >> 32), a1 = (short)(tx[q] >> 48), b0 = (short)(ty[q] >> 32), b1 = (short)(ty[q] >> 48);
+                    unsigned m = (unsigned)(resize_blend(sm[q], a0, a1, b0, b1, true) != 0) | nomask;
+                    unsigned p = (unsigned)resize_blend(sp[q], a0, a1, b0, b1, false) * m;
+                    if (pad[q]) { p = 0; m = 0; }
+                    if (i0 + q * SLAM_WG < n) {
+                        sp_part += p * p;
+                        tb[e[q]] = (unsigned char)p;
+                        tb[e[q] + 4] = m ? 0xFF : 0x00;
+                    }
                 }
             }
         }
@@ -605,16 +607,19 @@ __device__ __forceinline__ CoreOut mini_level(const Geo& g, const Tmpl& t, lds_u
         const int n = mp.trows * tp;
         const float rtp = __builtin_amdgcn_rcpf((float)tp);
         for (int i0 = lane; i0 < n; i0 += 4 * SLAM_WG) {
+            const int nq = min(4, (n - (i0 - lane) + SLAM_WG - 1) >> 6);    // dwords per lane in this pass (wave-uniform)
             unsigned v[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int i = min(i0 + q * SLAM_WG, n - 1);
-                const int r = (int)(((float)i + 0.5f) * rtp), c = i - r * tp;
-                v[q] = *reinterpret_cast<const unsigned*>(base + (long long)r * g.ipitch + 4 * c);
+                if (q < nq) {
+                    const int i = min(i0 + q * SLAM_WG, n - 1);
+                    const int r = (int)(((float)i + 0.5f) * rtp), c = i - r * tp;
+                    v[q] = *reinterpret_cast<const unsigned*>(base + (long long)r * g.ipitch + 4 * c);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (i0 + q * SLAM_WG < n) tile[i0 + q * SLAM_WG] = v[q];
+                if (q < nq && i0 + q * SLAM_WG < n) tile[i0 + q * SLAM_WG] = v[q];
         }
     }
     // at most 66051 template pixels: the whole sum of squares fits 32 bits

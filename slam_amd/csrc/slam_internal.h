@@ -17,7 +17,8 @@ struct slam_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     char err[512] = {0};
-    int match_lds_bytes = 12 * 1024;   // LDS per search job: 12 jobs share a CU's 160 KB, as many as its registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
+    int line_lds_bytes = 12 * 1024;    // the same for line walks: 12 jobs per CU (3 per SIMD), large descriptors
+    int match_lds_bytes = 9 * 1024;    // LDS per search job: 16 jobs share a CU's 160 KB, as many as its registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
     int force_direct = 0;   // SLAM_HIP_FORCE_DIRECT=1: search by direct evaluation (cross-check of the tiled core)
     // growable device staging buffers used by the host-table entry points
     void* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};
