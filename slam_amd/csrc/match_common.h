@@ -26,6 +26,13 @@ __device__ __forceinline__ void slam_stamp(int& slot, int id) {
 #define STAMP_DECL int stamp_slot = 0
 #define STAMP_ARG , int& stamp_slot
 #define STAMP_PASS , stamp_slot
+#elif defined(SLAM_DIAG_EXIT_AT)
+// diagnostic builds that end every wave at one phase boundary: the instruction counters of such a build, minus
+// those of the build that ends one boundary earlier, are the cost of the phase in between (never shipped)
+#define STAMP(id) do { if ((id) == SLAM_DIAG_EXIT_AT) __builtin_amdgcn_endpgm(); } while (0)
+#define STAMP_DECL ((void)0)
+#define STAMP_ARG
+#define STAMP_PASS
 #else
 #define STAMP(id) ((void)0)
 #define STAMP_DECL ((void)0)

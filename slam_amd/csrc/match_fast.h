@@ -187,6 +187,7 @@ __device__ __forceinline__ void stage_template(const Geo& g, const Tmpl& t, lds_
             else resize_tap(u0 + (i - G * 4), t.scale_y, t.srch, false, o, c0, c1);
             taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)o;
         }
+        STAMP(46);
         __syncthreads();
         STAMP(44);
         lds_u8* tb = reinterpret_cast<lds_u8*>(tmpl);
@@ -599,6 +600,7 @@ __device__ __forceinline__ CoreOut mini_level(const Geo& g, const Tmpl& t, lds_u
     lds_u64* tmpl = reinterpret_cast<lds_u64*>(lds);
     lds_u32* tile = reinterpret_cast<lds_u32*>(lds + g.ph * G * 8);
     unsigned long long sp_part = 0;
+    STAMP(45);
     __syncthreads();                                   // earlier readers of this LDS are done
     stage_template(g, t, tmpl, reinterpret_cast<lds_u64*>(tile), t.resized ? (G * 4 + g.ph) * 8 : 0, 0, g.ph, G, sp_part STAMP_PASS);
     STAMP(40);
