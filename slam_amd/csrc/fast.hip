@@ -290,16 +290,20 @@ __global__ __launch_bounds__(FAST_WG) void fast_tile_kernel(
                             M[q] = *reinterpret_cast<const fl_u32*>(row + 4 * lane - 4 + 4 * q);
                             D[q] = *reinterpret_cast<const fl_u32*>(row + FAST_CW + 4 * lane - 4 + 4 * q);
                         }
+                        // two pixels per operation, as in phase 1: pixels j = o and o + 2 as 16-bit halves; a score is
+                        // kept when it exceeds the largest of its 8 neighbours (a zero score never does)
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int s = win_byte(M[0], M[1], M[2], 4 + j);
-                            int nb = 0;                          // largest of the 8 neighbours
+                        for (int o = 0; o < 2; o++) {
+                            const fast_u2 s2 = ring_pair(M[0], M[1], M[2], 0, o);
+                            fast_u2 nb = __builtin_elementwise_max(ring_pair(M[0], M[1], M[2], -1, o), ring_pair(M[0], M[1], M[2], 1, o));
 #pragma unroll
                             for (int dx = -1; dx <= 1; dx++) {
-                                nb = max(nb, max(win_byte(U[0], U[1], U[2], 4 + j + dx), win_byte(D[0], D[1], D[2], 4 + j + dx)));
-                                if (dx != 0) nb = max(nb, win_byte(M[0], M[1], M[2], 4 + j + dx));
+                                nb = __builtin_elementwise_max(nb, ring_pair(U[0], U[1], U[2], dx, o));
+                                nb = __builtin_elementwise_max(nb, ring_pair(D[0], D[1], D[2], dx, o));
                             }
-                            if (s > nb) keep |= 1u << j;
+                            const fast_u2 hit = __builtin_elementwise_sub_sat(s2, nb);
+                            if (hit.x != 0) keep |= 1u << o;
+                            if (hit.y != 0) keep |= 4u << o;
                         }
                     } else {
 #pragma unroll
