@@ -231,14 +231,15 @@ __global__ __launch_bounds__(FAST_WG) void fast_tile_kernel(
             cand &= inside;
         }
         // append the candidates of these 256 pixels to the wavefront's list: (row in share << 8) | score column
+        // (the list's order is irrelevant: every entry is scored on its own)
         if (__ballot(cand != 0u) != 0ull) {
+            const unsigned mine = (unsigned)__popc(cand);
+            const unsigned incl = wave_scan_incl(mine);
+            int pos = n + (int)(incl - mine);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool c = (cand >> j) & 1u;
-                const unsigned long long bal = __ballot(c);
-                if (c) mylist[n + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)((rr << 8) | (4 * lane + j));
-                n += __popcll(bal);
-            }
+            for (int j = 0; j < 4; j++)
+                if ((cand >> j) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
+            n += __builtin_amdgcn_readlane((int)incl, 63);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
