@@ -46,7 +46,7 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     const char* fd = getenv("SLAM_HIP_FORCE_DIRECT");
     c->force_direct = (fd && fd[0] == '1') ? 1 : 0;
     const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");
-    if (lk && atoi(lk) >= 4 && atoi(lk) <= 64) c->match_lds_bytes = c->line_lds_bytes = atoi(lk) * 1024;
+    if (lk && atoi(lk) >= 4 && atoi(lk) <= 63) c->match_lds_bytes = c->line_lds_bytes = atoi(lk) * 1024;
     *out = c;
     return SLAM_HIP_OK;
 }
@@ -70,8 +70,8 @@ extern "C" int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream) {
 
 extern "C" int slam_hip_set_match_lds(slam_ctx* ctx, int bytes) {
     if (!ctx) return SLAM_HIP_EINVAL;
-    if (bytes < 4096 || bytes > 65536 || (bytes & 1023))
-        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_match_lds: %d not a multiple of 1024 in [4096, 65536]", bytes);
+    if (bytes < 4096 || bytes > 64512 || (bytes & 1023))      // the walk kernel adds 576 B of static LDS: 64 KB per workgroup in all
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_match_lds: %d not a multiple of 1024 in [4096, 64512]", bytes);
     ctx->match_lds_bytes = bytes;
     ctx->line_lds_bytes = bytes;
     return SLAM_HIP_OK;

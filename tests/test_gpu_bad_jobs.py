@@ -103,4 +103,5 @@ def test_host_entry_points_reject_unusable_arguments(ctx):
     finally:
         L.slam_hip_pyramid_destroy(ctx.handle, pyr)
     assert L.slam_hip_set_match_lds(ctx.handle, 1000) == capi.EINVAL
+    assert L.slam_hip_set_match_lds(ctx.handle, 65536) == capi.EINVAL      # with the kernels' static LDS it would pass 64 KB
     assert L.slam_hip_set_match_lds(ctx.handle, 10240) == 0      # back to the default
