@@ -262,7 +262,7 @@ int pyr_launch(slam_ctx* ctx, const uint8_t* src, int sw, int sh, size_t spitch,
         L.span = lev[l].plan.span; L.unit0 = units;
         L.box = (lev[l].plan.box && ((((uintptr_t)src | spitch | sstride) & 15) == 0)) ? lev[l].plan.box : 0;
         units += L.ncolt * L.nband;
-        lds = std::max(lds, lev[l].plan.lds);
+        if (!L.box) lds = std::max(lds, lev[l].plan.lds);     // box levels stage nothing and need no LDS
     }
     a.units = units;
     const long long groups = ((long long)nframes + 7) / 8;
