@@ -89,8 +89,11 @@ __device__ __forceinline__ void fast_arc_scores(const fl_u8* p, int pitch, int& 
     fast_s2 e[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int r = p[ring_dy(k) * pitch + ring_dx(k)];
-        e[k] = fast_s2{(short)(v - r), (short)(r - v)};
+        // (v - r, r - v) from the pair (v, r) with one packed subtraction whose operands are the pair and its swap
+        const unsigned vr = (unsigned)v | ((unsigned)p[ring_dy(k) * pitch + ring_dx(k)] << 16);
+        unsigned d;
+        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(vr));
+        e[k] = __builtin_bit_cast(fast_s2, d);
     }
     fast_s2 m2[16], m4[16], m8[16];
 #pragma unroll
