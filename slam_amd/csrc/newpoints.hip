@@ -12,33 +12,45 @@ namespace {
 
 constexpr int NP_WG = 256;
 
+constexpr int NP_SUPER = 2048;      // keys one workgroup places
+
 // Stable counting sort by response.  cv::FAST's output is row-major, i.e. already ordered by (y, x),
 // and responses are integers in [0, 255]: a stable sort by descending response therefore yields the
-// order (response desc, y asc, x asc).  One workgroup per frame walks the list in groups of 256 keys:
-// per group each wavefront ranks its keys among equal responses (one ballot per distinct value),
-// publishes per-wavefront bucket counts, and the destination is
-//   bucket base + keys of that bucket in earlier groups + in earlier wavefronts + rank.
+// order (response desc, y asc, x asc).  A frame's list is cut into runs of NP_SUPER keys, one workgroup each
+// (no scratch memory, no ordering between workgroups): the workgroup first counts, over the whole list, the
+// keys of every response value and those of them that precede its run - that fixes where each value's keys
+// of this run start - and then walks its run in groups of 256 keys: per group each wavefront ranks its keys
+// among equal responses (one ballot per distinct value), publishes per-wavefront bucket counts, and the
+// destination is
+//   start of the value + keys of that value in earlier groups + in earlier wavefronts + rank.
 __global__ __launch_bounds__(NP_WG) void sort_kernel(const slam_keypoint* __restrict__ in, const int* __restrict__ counts,
                                                      int cap, slam_keypoint* __restrict__ out) {
     __shared__ unsigned base[256];          // next free output slot of each response value
+    __shared__ unsigned before[256];        // keys of each value ahead of this run
     __shared__ unsigned wcnt[4][256];       // keys per (wavefront, response) in the current group
     const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n = min(counts[frame], cap);
+    const int run0 = blockIdx.y * NP_SUPER, run1 = min(n, run0 + NP_SUPER);
+    if (run0 >= n) return;
     const slam_keypoint* src = in + (size_t)frame * cap;
     slam_keypoint* dst = out + (size_t)frame * cap;
-    base[tid] = 0u;
+    base[tid] = 0u; before[tid] = 0u;
     for (int k = 0; k < 4; k++) wcnt[k][tid] = 0u;
     __syncthreads();
-    for (int i = tid; i < n; i += NP_WG) atomicAdd(&base[min(max((int)src[i].response, 0), 255)], 1u);
+    for (int i = tid; i < n; i += NP_WG) {
+        const int bkt = min(max((int)src[i].response, 0), 255);
+        atomicAdd(&base[bkt], 1u);
+        if (i < run0) atomicAdd(&before[bkt], 1u);
+    }
     __syncthreads();
     if (tid == 0) {                         // descending response: bucket 255 first
         unsigned run = 0;
-        for (int b = 255; b >= 0; b--) { const unsigned c = base[b]; base[b] = run; run += c; }
+        for (int b = 255; b >= 0; b--) { const unsigned c = base[b]; base[b] = run + before[b]; run += c; }
     }
     __syncthreads();
-    for (int g0 = 0; g0 < n; g0 += NP_WG) {
+    for (int g0 = run0; g0 < run1; g0 += NP_WG) {
         const int i = g0 + tid;
-        const bool valid = i < n;
+        const bool valid = i < run1;
         slam_keypoint kp = {0.f, 0.f, 0.f};
         if (valid) kp = src[i];
         const int b = min(max((int)kp.response, 0), 255);
@@ -150,7 +162,8 @@ extern "C" int slam_hip_sort_keypoints_d(slam_ctx* ctx, const slam_keypoint* d_i
     if (!d_in || !d_counts || !d_out || d_in == d_out || nframes < 1 || cap_per_frame < 1)
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "sort_keypoints: bad arguments");
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(sort_kernel, dim3(nframes), dim3(NP_WG), 0, ctx->stream, d_in, d_counts, cap_per_frame, d_out);
+    hipLaunchKernelGGL(sort_kernel, dim3(nframes, (cap_per_frame + NP_SUPER - 1) / NP_SUPER), dim3(NP_WG), 0, ctx->stream, d_in,
+                       d_counts, cap_per_frame, d_out);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }
