@@ -104,3 +104,33 @@ def test_batched_device_path_c4(ctx, oracle):
         assert cnt[f] == len(ref_k) and np.array_equal(srt[f, :cnt[f]], ref_k)
         ref_sel = oracle.select_new_points(ref_k, occ[occ_off[f]:occ_off[f + 1]], n_new, 12.0, r, r, w, h)
         assert nsel[f] == len(ref_sel) and np.array_equal(sel[f, :nsel[f]], ref_sel)
+
+
+def test_sort_is_stable_across_run_boundaries(ctx, oracle):
+    """Crafted lists around the 2048-key runs one workgroup places: lengths 0, 1, 2047, 2048, 2049 and 10 000, few
+    distinct responses (long ties, whose row-major order must survive) and all 256 of them, counts beyond the
+    capacity (clamped) - each frame against the oracle's order (response desc, then the input order)."""
+    rng = np.random.default_rng(8)
+    cap = 10240
+    lens = [0, 1, 2047, 2048, 2049, 10000, 6000, 20000]
+    nfr = len(lens)
+    kps = np.zeros((nfr, cap, 3), np.float32)
+    for f, n in enumerate(lens):
+        m = min(n, cap)
+        hi = [256, 256, 3, 256, 1, 256, 7, 256][f]
+        kps[f, :m, 0] = np.arange(m) % 1900            # x, y increasing in row-major order like cv::FAST's output
+        kps[f, :m, 1] = np.arange(m) // 1900
+        kps[f, :m, 2] = rng.integers(0, hi, m)
+    counts = np.array(lens, np.int32)
+    L = capi.lib()
+    d_in, d_c, d_out = DevBuf(ctx, kps), DevBuf(ctx, counts), DevBuf(ctx, nbytes=kps.nbytes, fill=0xCD)
+    capi.check(ctx.handle, L.slam_hip_sort_keypoints_d(ctx.handle, d_in.ptr, d_c.ptr, nfr, cap, d_out.ptr))
+    ctx.synchronize()
+    got = d_out.get(np.float32).reshape(nfr, cap, 3)
+    for b in (d_in, d_c, d_out):
+        b.free()
+    for f, n in enumerate(lens):
+        m = min(n, cap)
+        ref = oracle.sort_keypoints(kps[f, :m])
+        assert np.array_equal(got[f, :m], ref), f
+        assert (got[f, m:].view(np.uint32) == 0xCDCDCDCD).all()        # nothing written beyond the list
