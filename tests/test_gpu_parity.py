@@ -215,6 +215,7 @@ def test_reference_property_test(ctx, oracle, use_am, use_pm):
     for c in cases:
         if c["w"] * c["h"] <= 80 * 80:
             _check_match(ctx, oracle, c["im"], c["patch"], c["patch_mask"], c["area"], c["area_mask"], 1)
+    accepted = 0
     for c in cases:
         pyr = api.ImagePyramid(ctx, c["im"], [1.0])
         try:
@@ -226,7 +227,34 @@ def test_reference_property_test(ctx, oracle, use_am, use_pm):
         ref = oracle.match(c["im"], c["patch"], c["patch_mask"], c["area"], c["area_mask"], 1)
         assert (got["x"], got["y"]) == (ref["x"], ref["y"])
         assert _same_float(got["response"], ref["response"])
-        assert oracle.PropTest.accept(c, got["x"], got["y"], got["response"])
+        accepted += bool(oracle.PropTest.accept(c, got["x"], got["y"], got["response"]))
+    # The property itself (the planted patch, or an exact duplicate, is found) belongs to the algorithm, not to this
+    # implementation: normalised correlation also scores 1 on a window proportional to the patch, so a stream
+    # reseeded per mode may hold a trial that breaks it (one of 400 does in the two-mask mode, for the oracle too).
+    # The reference's own 4 x 100 trials are replayed, property asserted, in the next test.
+    assert accepted >= ntrials - max(1, ntrials // 100)
+
+
+def test_reference_tests_replayed_as_one_stream(ctx, oracle):
+    """tests/tests.cpp:11-17 runs test_matching, ..Area, ..Patch and ..PatchArea back to back in one process, so the
+    unseeded glibc rand() stream runs through all 400 trials; replayed here in that order through the HIP path, every
+    trial must satisfy the reference's own acceptance rule (tests/test_matching.cpp:83-98)."""
+    pt = None
+    for use_am, use_pm in [(0, 0), (1, 0), (0, 1), (1, 1)]:
+        if pt is None:
+            pt = oracle.PropTest(use_am, use_pm, seed=1)
+        else:
+            pt.uam, pt.upm = int(use_am), int(use_pm)          # same stream, the next test's switches
+        for k in range(100):
+            c = pt.next()
+            pyr = api.ImagePyramid(ctx, c["im"], [1.0])
+            try:
+                got = api.match_batch(ctx, pyr, [dict(patch=c["patch"], patch_mask=c["patch_mask"], area=c["area"],
+                                                      area_mask=c["area_mask"], stride=1)])[0]
+            finally:
+                pyr.close()
+            assert got["status"] == 0
+            assert oracle.PropTest.accept(c, got["x"], got["y"], got["response"]), (use_am, use_pm, k, got)
 
 
 def _c2_like_jobs(rng, w, h, nfeat, tsize, frame0, shift):
