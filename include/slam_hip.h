@@ -366,7 +366,8 @@ typedef struct slam_ellipse_job {
     int64_t mask_off;                 /* mask in the blob, pitch w; every byte of it is written (0 or 255) */
     int32_t x, y, w, h;               /* the window, in pixels of the level it was set up for */
     float   ux, uy;                   /* ellipse centre relative to (x, y) */
-    float   q11, q12, q22;            /* inside <=> q11*dx*dx + 2*q12*dx*dy + q22*dy*dy <= 1 (float, this order) */
+    float   q11, q12, q22;            /* inside <=> q11*dx*dx + 2*q12*dx*dy + q22*dy*dy <= 1 (float, this order),
+                                         or the pixel is the one nearest the centre: (floor(ux+.5), floor(uy+.5)) */
     int32_t valid;                    /* 0: no window (degenerate covariance or larger than the cap) */
 } slam_ellipse_job;
 

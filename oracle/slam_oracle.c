@@ -813,6 +813,7 @@ int so_ellipse_setup(float px, float py, const float* cov, float gate, float res
 int so_ellipse_mask(const so_ellipse* e, uint8_t* mask) {
     if (!e || !mask || !e->valid || e->w < 1 || e->h < 1) return -1;
     const float q12x2 = e->q12 + e->q12;
+    const int cxn = (int)floorf(e->ux + 0.5f), cyn = (int)floorf(e->uy + 0.5f);   /* nearest pixel: always inside */
     for (int y = 0; y < e->h; y++)
         for (int x = 0; x < e->w; x++) {
             const float dx = (float)x - e->ux, dy = (float)y - e->uy;
@@ -820,7 +821,7 @@ int so_ellipse_mask(const so_ellipse* e, uint8_t* mask) {
             const float t1 = (q12x2 * dx) * dy;
             const float t2 = (e->q22 * dy) * dy;
             const float t = (t0 + t1) + t2;
-            mask[(size_t)y * e->w + x] = t <= 1.f ? 255 : 0;
+            mask[(size_t)y * e->w + x] = (t <= 1.f || (x == cxn && y == cyn)) ? 255 : 0;
         }
     return 0;
 }

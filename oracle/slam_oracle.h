@@ -166,7 +166,8 @@ int so_project(const uint8_t* descr, int dw, int dh, ptrdiff_t dpitch, const flo
 typedef struct so_ellipse {
     int x, y, w, h;
     float ux, uy;          /* centre relative to (x, y) */
-    float q11, q12, q22;   /* inside <=> q11 dx^2 + 2 q12 dx dy + q22 dy^2 <= 1, evaluated in float */
+    float q11, q12, q22;   /* inside <=> q11 dx^2 + 2 q12 dx dy + q22 dy^2 <= 1, evaluated in float, or the pixel
+                              nearest the centre */
     int valid;
 } so_ellipse;
 int so_ellipse_setup(float px, float py, const float* cov, float gate, float res, so_ellipse* out);

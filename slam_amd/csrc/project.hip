@@ -441,13 +441,15 @@ __global__ __launch_bounds__(WARP_WG) void ellipse_mask_kernel(const slam_ellips
     uint8_t* M = blob + job.mask_off;
     const int total = job.w * job.h;
     const float q12x2 = __fadd_rn(job.q12, job.q12);
+    // the pixel nearest the centre always belongs to the window, however small the ellipse
+    const int nx = (int)floorf(__fadd_rn(job.ux, 0.5f)), ny = (int)floorf(__fadd_rn(job.uy, 0.5f));
     for (int i = blockIdx.y * WARP_WG + threadIdx.x; i < total; i += gridDim.y * WARP_WG) {
         const int y = i / job.w, x = i - y * job.w;
         const float dx = __fsub_rn((float)x, job.ux), dy = __fsub_rn((float)y, job.uy);
         const float a = __fmul_rn(__fmul_rn(job.q11, dx), dx);
         const float b = __fmul_rn(__fmul_rn(q12x2, dx), dy);
         const float c = __fmul_rn(__fmul_rn(job.q22, dy), dy);
-        M[i] = __fadd_rn(__fadd_rn(a, b), c) <= 1.f ? 255 : 0;
+        M[i] = (__fadd_rn(__fadd_rn(a, b), c) <= 1.f || (x == nx && y == ny)) ? 255 : 0;
     }
 }
 

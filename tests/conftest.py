@@ -29,3 +29,8 @@ def ctx():
     c = api.Context(0)
     yield c
     c.close()
+
+
+# Added to the seeds of the randomised differential tests (SLAM_TEST_SEED=n python -m pytest ...): other inputs,
+# same checks - for soak runs beyond the default stream.
+SOAK_SEED = int(os.environ.get("SLAM_TEST_SEED", "0"))

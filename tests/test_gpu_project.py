@@ -7,6 +7,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import SOAK_SEED
+
 from slam_amd import api, capi, synth
 
 pytestmark = pytest.mark.gpu
@@ -63,7 +65,7 @@ def _rand_homography(rng, dw, dh, ow, oh, persp=2e-3):
 
 
 def test_warp_random_homographies(ctx, oracle):
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SOAK_SEED)
     cases = []
     for i in range(160):
         dw, dh = int(rng.integers(1, 90)), int(rng.integers(1, 90))
@@ -88,7 +90,7 @@ def test_warp_random_homographies(ctx, oracle):
 def test_warp_degenerate_maps(ctx, oracle):
     """Zero denominators (W = 0 -> coordinate 0), coordinates beyond the short and int ranges, exact half steps
     (round-half-even), maps that miss the descriptor entirely, and jobs the device must reject."""
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(12 + SOAK_SEED)
     d = rng.integers(1, 256, (23, 31), dtype=np.uint8)
     Ms = [
         np.zeros((3, 3)),                                              # W = 0 everywhere: every pixel reads descriptor (0,0)
