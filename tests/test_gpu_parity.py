@@ -390,6 +390,32 @@ def test_fast_matches_oracle(ctx, oracle, w, h):
             assert _kp_set(got[f]) == _kp_set(ref), (w, h, thr, nms, f)   # same set AND same (row-major) order
 
 
+def test_fast_random_images_against_oracle(ctx, oracle):
+    """Differential test of FAST + NMS over random sizes (down to the 7x7 minimum, across the 248-column and 30-row
+    tile seams), thresholds, both NMS settings and textures that stress ties: flat areas, steps, coarse noise with
+    many equal scores, saturated pixels."""
+    rng = np.random.default_rng(4242 + SOAK_SEED)
+    for it in range(24):
+        w, h = int(rng.integers(7, 600)), int(rng.integers(7, 130))
+        kind = it % 4
+        if kind == 0:
+            im = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1:                                                  # few grey levels: many tied scores for the NMS
+            im = (rng.integers(0, 4, (h, w)) * 60).astype(np.uint8)
+        elif kind == 2:                                                  # blocks with sharp steps and saturated values
+            b = rng.integers(0, 2, ((h + 5) // 6, (w + 7) // 8)).astype(np.uint8) * 255
+            im = np.kron(b, np.ones((6, 8), np.uint8))[:h, :w].copy()
+            im[rng.random((h, w)) < 0.02] = 128
+        else:
+            im = synth.frame(w, h, 900 + it + SOAK_SEED) if w >= 32 and h >= 32 else np.full((h, w), 77, np.uint8)
+        thr = int(rng.choice([0, 1, 5, 10, 20, 60, 200, 255]))
+        nms = bool(rng.integers(0, 2))
+        ref = oracle.fast(im, thr, nms)
+        got, counts, rc = api.fast(ctx, im, thr, nms)
+        assert counts[0] == len(ref), (it, w, h, thr, nms)
+        assert np.array_equal(got[0], ref.astype(np.float32)), (it, w, h, thr, nms)
+
+
 def test_fast_capacity_is_reported(ctx, oracle):
     frame = synth.frame(320, 240, 3)
     ref = oracle.fast(frame, 10, True)
