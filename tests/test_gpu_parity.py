@@ -108,6 +108,36 @@ def test_pyramid_matches_oracle(ctx, oracle, w, h, subs):
         pyr.close()
 
 
+def test_pyramid_random_shapes_against_oracle(ctx, oracle):
+    """Differential test of the pyramid build over random frame sizes (odd, tiny, multiples of 16 that take the exact
+    2x / 4x / 8x path) and random increasing subsample lists with fractional factors, 1 to 3 frames per batch."""
+    rng = np.random.default_rng(515 + SOAK_SEED)
+    for it in range(16):
+        if it % 3 == 0:
+            w, h = 16 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 40))
+            subs = [1.0] + sorted(rng.choice([2.0, 4.0, 8.0], int(rng.integers(1, 4)), replace=False).tolist())
+        else:
+            w, h = int(rng.integers(8, 700)), int(rng.integers(8, 500))
+            k = int(rng.integers(1, 5))
+            subs = sorted(set(np.round(rng.uniform(1.0, 7.0, k), 2).tolist()))
+            if rng.integers(0, 2):
+                subs = [1.0] + [s for s in subs if s > 1.0]
+        subs = [s for s in subs if round(w / s) >= 1 and round(h / s) >= 1]
+        if not subs:
+            continue
+        nfr = int(rng.integers(1, 4))
+        frames = rng.integers(0, 256, (nfr, h, w), dtype=np.uint8)
+        pyr = api.ImagePyramid(ctx, frames, subs)
+        try:
+            for f in range(nfr):
+                ref = oracle.pyramid(frames[f], subs)
+                for l in range(len(subs)):
+                    got = pyr.image(l, f)
+                    assert got.shape == ref[l].shape and np.array_equal(got, ref[l]), (it, w, h, subs, f, l)
+        finally:
+            pyr.close()
+
+
 def _rand_case(rng, w, h, pwmax, awmax):
     im = rng.integers(0, 256, (h, w), dtype=np.uint8)
     pw, ph = int(rng.integers(1, pwmax + 1)), int(rng.integers(1, pwmax + 1))
