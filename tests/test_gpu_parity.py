@@ -165,6 +165,28 @@ def test_match_random_small_all_modes(ctx, oracle, use_pm, use_am):
         _check_match(ctx, oracle, im, patch, pm, area, am, stride, exact)
 
 
+@pytest.mark.parametrize("use_pm,use_am", [(False, False), (False, True), (True, False), (True, True)])
+def test_match_random_medium_all_modes(ctx, oracle, use_pm, use_am):
+    """Larger random searches: windows of hundreds to thousands of cells (several blocks, the two-pass score
+    finalisation, border lattices on every side), templates up to 45 pixels, low-entropy images that produce tied
+    and near-tied maxima."""
+    rng = np.random.default_rng(300 + 2 * use_pm + use_am + SOAK_SEED)
+    for it in range(14):
+        w, h = int(rng.integers(30, 200)), int(rng.integers(30, 160))
+        im, patch, area = _rand_case(rng, w, h, 45, 110)
+        if it % 4 == 1:                                                   # few grey levels: ties between cells
+            im = (im >> 6 << 6).astype(np.uint8)
+            patch = (patch >> 6 << 6).astype(np.uint8)
+        if it % 2 == 0:
+            ph, pw = patch.shape
+            if pw <= w and ph <= h:
+                x = int(rng.integers(0, w - pw + 1)); y = int(rng.integers(0, h - ph + 1))
+                patch = im[y:y + ph, x:x + pw].copy()
+        pm = (rng.random(patch.shape) < 0.8).astype(np.uint8) if use_pm else None
+        am = (rng.random((area[3], area[2])) < 0.7).astype(np.uint8) if use_am else None
+        _check_match(ctx, oracle, im, patch, pm, area, am, int(rng.integers(1, 5)), bool(rng.integers(0, 2)))
+
+
 def test_match_edge_cases(ctx, oracle):
     rng = np.random.default_rng(5)
     im = rng.integers(0, 256, (30, 40), dtype=np.uint8)
