@@ -87,7 +87,7 @@ __device__ __forceinline__ void box_tile(const uint8_t* __restrict__ src, long l
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(256) void pyr_build_kernel(PyrArgs a) {
+__global__ __launch_bounds__(256, ALIGNED ? 8 : 5) void pyr_build_kernel(PyrArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pyr_lds[];
     const unsigned per = 8u * (unsigned)a.units;
     const unsigned fg = blockIdx.x / per, rem = blockIdx.x - fg * per;
