@@ -55,9 +55,13 @@ __global__ __launch_bounds__(WARP_WG) void warp_kernel(const uint8_t* __restrict
     uint8_t* K = job.mask_off >= 0 ? out + job.mask_off : nullptr;
     const int total = (int)npix;
     const int nthr = blockDim.x;                  // 64 for batches of small outputs, WARP_WG otherwise
+    // floor(n / d) through one reciprocal: exact while n < 2^20 ((n + 0.5) / d stays 0.5/d away from an integer, far
+    // more than the float error at these magnitudes); larger outputs take the integer division
+    const bool small = total < (1 << 20);
+    const float row = __builtin_amdgcn_rcpf((float)ow), rbw = __builtin_amdgcn_rcpf((float)bw0);
     for (int i = blockIdx.y * nthr + threadIdx.x; i < total; i += gridDim.y * nthr) {
-        const int y = i / ow, x = i - y * ow;
-        const int xb = (x / bw0) * bw0, x1 = x - xb;
+        const int y = small ? (int)(((float)i + 0.5f) * row) : i / ow, x = i - y * ow;
+        const int xb = (int)(((float)x + 0.5f) * rbw) * bw0, x1 = x - xb;
         const double X0 = M0 * xb + M1 * y + M2;
         const double Y0 = M3 * xb + M4 * y + M5;
         const double W0 = M6 * xb + M7 * y + M8;

@@ -87,6 +87,20 @@ def test_warp_random_homographies(ctx, oracle):
         assert st == 0 and m2 is None and np.array_equal(p1, p2)
 
 
+def test_warp_large_outputs(ctx, oracle):
+    """Outputs of more than 2^20 pixels (the kernel splits the pixel index differently there) and the 4096 limit."""
+    rng = np.random.default_rng(13 + SOAK_SEED)
+    d = rng.integers(0, 256, (120, 150), dtype=np.uint8)
+    cases = [(d, _rand_homography(rng, 150, 120, ow, oh, persp=2e-5), ow, oh) for (ow, oh) in [(1100, 1000), (4096, 300), (257, 4096)]]
+    got = _warp_batch(ctx, cases, hint=4096 * 300)
+    for (dd, M, ow, oh), (p, m, st) in zip(cases, got):
+        assert st == 0
+        assert np.array_equal(p, oracle.warp_perspective(dd, M, ow, oh, False)), (ow, oh)
+        assert np.array_equal(m, oracle.warp_perspective(np.ones_like(dd), M, ow, oh, True)), (ow, oh)
+    r = _warp_batch(ctx, [(d, np.eye(3, dtype=np.float32), 4097, 2)])
+    assert r[0][2] == capi.EINVAL
+
+
 def test_warp_degenerate_maps(ctx, oracle):
     """Zero denominators (W = 0 -> coordinate 0), coordinates beyond the short and int ranges, exact half steps
     (round-half-even), maps that miss the descriptor entirely, and jobs the device must reject."""
