@@ -315,9 +315,11 @@ __global__ __launch_bounds__(WARP_WG) void disc_mask_kernel(const int32_t* __res
     const int total = (int)npix;
     const int span = gridDim.y * WARP_WG;
     const int iters = (total + span - 1) / span;                            // the same for every lane: barriers inside
+    const bool small = total + span < (1 << 20);                            // then (i + 0.5) / w through a reciprocal is exact
+    const float rw = __builtin_amdgcn_rcpf((float)job.w);
     for (int it = 0; it < iters; it++) {
         const int i = it * span + blockIdx.y * WARP_WG + threadIdx.x;
-        const int y = i / job.w, x = i - y * job.w;
+        const int y = small ? (int)(((float)i + 0.5f) * rw) : i / job.w, x = i - y * job.w;
         bool in = false;
         for (int c0 = 0; c0 < job.circle_count; c0 += CHUNK) {
             const int nc = min(CHUNK, job.circle_count - c0);
@@ -447,8 +449,9 @@ __global__ __launch_bounds__(WARP_WG) void ellipse_mask_kernel(const slam_ellips
     const float q12x2 = __fadd_rn(job.q12, job.q12);
     // the pixel nearest the centre always belongs to the window, however small the ellipse
     const int nx = (int)floorf(__fadd_rn(job.ux, 0.5f)), ny = (int)floorf(__fadd_rn(job.uy, 0.5f));
+    const float rw = __builtin_amdgcn_rcpf((float)job.w);     // total <= 300 * 300: the reciprocal quotient is exact
     for (int i = blockIdx.y * WARP_WG + threadIdx.x; i < total; i += gridDim.y * WARP_WG) {
-        const int y = i / job.w, x = i - y * job.w;
+        const int y = (int)(((float)i + 0.5f) * rw), x = i - y * job.w;
         const float dx = __fsub_rn((float)x, job.ux), dy = __fsub_rn((float)y, job.uy);
         const float a = __fmul_rn(__fmul_rn(job.q11, dx), dx);
         const float b = __fmul_rn(__fmul_rn(q12x2, dx), dy);
