@@ -55,10 +55,30 @@ struct BlockArgs {
     bool border;
 };
 
+// One 4-pixel group of one template row for the 4 cells of a strip.  MASKED: the window is masked before its energy
+// is summed; without a patch mask only the last group of a row (columns beyond the template width) needs that.
+template <bool BORDER, bool MASKED>
+__device__ __forceinline__ void strip_group(unsigned d0, unsigned dn, unsigned v0, unsigned vn, unsigned long long pm,
+                                            unsigned (&cc)[4], unsigned (&si)[4], unsigned (&sp)[4]) {
+    const unsigned P0 = (unsigned)pm, M = (unsigned)(pm >> 32);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned w = (k == 0) ? d0 : __builtin_amdgcn_alignbyte(dn, d0, k);
+        const unsigned wm = MASKED ? (w & M) : w;
+        cc[k] = __builtin_amdgcn_udot4(w, P0, cc[k], false);      // P0 is already masked
+        si[k] = __builtin_amdgcn_udot4(wm, wm, si[k], false);
+        if (BORDER) {
+            const unsigned vm = (k == 0) ? v0 : __builtin_amdgcn_alignbyte(vn, v0, k);
+            sp[k] = __builtin_amdgcn_udot4(P0 & vm, P0, sp[k], false);
+        }
+    }
+}
+
 // Accumulate template rows [ub, ue) (chunk-relative) for the 4 cells of one strip.  Tile row r
 // holds image row (first image row of the tile) + r and the cell row `row` is relative to the
-// block, so template row u of that cell lies in tile row row + u.
-template <bool BORDER>
+// block, so template row u of that cell lies in tile row row + u.  ALLKEPT: no patch mask, so every
+// group but the last of a row keeps all four pixels.
+template <bool BORDER, bool ALLKEPT>
 __device__ __forceinline__ void strip_accumulate(const lds_u32* tile, const lds_u32* vtile, int tp,
                                                  const lds_u64* tmpl, int G, int ub, int ue, int row, int strip,
                                                  unsigned (&cc)[4], unsigned (&si)[4], unsigned (&sp)[4]) {
@@ -69,24 +89,18 @@ __device__ __forceinline__ void strip_accumulate(const lds_u32* tile, const lds_
         const lds_u64* pr = tmpl + u * G;
         unsigned d0 = tr[0];
         unsigned v0 = BORDER ? vr[0] : 0u;
+        const int Gfull = ALLKEPT ? G - 1 : G;
 #pragma unroll 2
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < Gfull; ++g) {
             const unsigned dn = tr[g + 1];
-            const unsigned long long pm = pr[g];
-            const unsigned P0 = (unsigned)pm, M = (unsigned)(pm >> 32);
             const unsigned vn = BORDER ? vr[g + 1] : 0u;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned w = (k == 0) ? d0 : __builtin_amdgcn_alignbyte(dn, d0, k);
-                const unsigned wm = w & M;
-                cc[k] = __builtin_amdgcn_udot4(w, P0, cc[k], false);      // P0 is already masked
-                si[k] = __builtin_amdgcn_udot4(wm, wm, si[k], false);
-                if (BORDER) {
-                    const unsigned vm = (k == 0) ? v0 : __builtin_amdgcn_alignbyte(vn, v0, k);
-                    sp[k] = __builtin_amdgcn_udot4(P0 & vm, P0, sp[k], false);
-                }
-            }
+            strip_group<BORDER, !ALLKEPT>(d0, dn, v0, vn, pr[g], cc, si, sp);
             d0 = dn; v0 = vn;
+        }
+        if (ALLKEPT) {
+            const unsigned dn = tr[G];
+            const unsigned vn = BORDER ? vr[G] : 0u;
+            strip_group<BORDER, true>(d0, dn, v0, vn, pr[G - 1], cc, si, sp);
         }
     }
 }
@@ -361,8 +375,9 @@ __device__ __forceinline__ void fast_block(const Geo& g, const Tmpl& t, float* s
             const int row = small_div(unit, strips), strip = unit - row * strips;
             const int ub = small_div(slice * ur, S), ue = small_div((slice + 1) * ur, S);
             unsigned cc[4] = {0, 0, 0, 0}, si[4] = {0, 0, 0, 0}, sp[4] = {0, 0, 0, 0};
-            if (ba.border) strip_accumulate<true>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
-            else strip_accumulate<false>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
+            if (ba.border) strip_accumulate<true, false>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
+            else if (g.masked) strip_accumulate<false, false>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
+            else strip_accumulate<false, true>(tile, vtile, tp, tmpl, G, ub, ue, row, strip, cc, si, sp);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int a = (unit * FAST_J + k) * AW;
