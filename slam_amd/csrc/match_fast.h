@@ -525,6 +525,10 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         if (TR - UR + 1 >= 4 || UR == 1) BH = max(1, min(BH, TR - UR + 1));
         else { UR = max(1, TR / 2); BH = max(1, min(BH, TR - UR + 1)); }
     }
+    if (BH < g.ah) {                                       // several row blocks: equal heights instead of a thin last one
+        const int nblk = small_div_u(g.ah + BH - 1, BH);
+        BH = small_div_u(g.ah + nblk - 1, nblk);
+    }
     fs.valid = false; fs.big = big;
     STAMP(4);
     bool first = true, refine = false;
