@@ -516,7 +516,7 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
     // does any cell's patch leave the image?  Then blocks may need the validity tile and a third sum.
     const bool any_border = g.xl0 > 0 || g.yl0 > 0 || g.xl1 < g.aw || g.yl1 < g.ah;
     const int tp_max = (strips_max + G) | 1;
-    const int TR = max(1, small_div_u((lp.tile_bytes >> 2) >> (any_border ? 1 : 0), tp_max));
+    int TR = max(1, small_div_u((lp.tile_bytes >> 2) >> (any_border ? 1 : 0), tp_max));
     const int cap_rows = max(1, small_div_u(small_div_u(lp.acc_bytes >> (big ? 3 : 2), any_border ? 3 : 2), BW));
     int UR = max(1, min(min(g.ph, small_div_u(lp.tmpl_bytes / 8, G)), TR));
     int BH = min(g.ah, cap_rows);
@@ -524,6 +524,25 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         // prefer whole-template chunks: shrink the block first, then the chunk
         if (TR - UR + 1 >= 4 || UR == 1) BH = max(1, min(BH, TR - UR + 1));
         else { UR = max(1, TR / 2); BH = max(1, min(BH, TR - UR + 1)); }
+    }
+    // A window that needs several row blocks under the fixed split gets the job's LDS re-split to its own shapes:
+    // the template chunk keeps what it uses, and accumulators and tile share the rest so that a block is as tall
+    // as both allow (small templates leave most of the fixed template and tile shares idle).
+    LdsPlan lq = lp;
+    if (BH < g.ah) {
+        const int total = lp.acc_bytes + lp.tmpl_bytes + lp.tile_bytes;
+        const int A = BW * (big ? 8 : 4) * (any_border ? 3 : 2);          // accumulator bytes per block row
+        const int T = tp_max * 4 * (any_border ? 2 : 1);                  // tile (and validity) bytes per tile row
+        const int tb = (UR * G * 8 + 15) & ~15;
+        const int rest = total - tb - 32;
+        const int bh2 = small_div_u(max(rest - (UR - 1) * T, 0), A + T);
+        if (bh2 > BH) {
+            BH = min(g.ah, bh2);
+            lq.tmpl_bytes = tb;
+            lq.acc_bytes = (BH * A + 15) & ~15;
+            lq.tile_bytes = (total - lq.tmpl_bytes - lq.acc_bytes) & ~15;
+            TR = max(1, small_div_u((lq.tile_bytes >> 2) >> (any_border ? 1 : 0), tp_max));
+        }
     }
     if (BH < g.ah) {                                       // several row blocks: equal heights instead of a thin last one
         const int nblk = small_div_u(g.ah + BH - 1, BH);
@@ -564,7 +583,7 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         const int URb = refine ? max(1, min(UR, TR - ba.bh + 1)) : UR;     // the 3-row refine block must fit the tile
         const int S = pick_slices(ba.strips * ba.bh, URb);
         STAMP(5);
-        fast_block(g, t, refine ? nullptr : scores, lds, lp, ba, URb, S, G, big, first, !refine, spfull, nm, best STAMP_PASS);
+        fast_block(g, t, refine ? nullptr : scores, lds, lq, ba, URb, S, G, big, first, !refine, spfull, nm, best STAMP_PASS);
         first = false;
         nblocks++;
         fs.ba = ba;
