@@ -51,8 +51,8 @@ int slam_hip_destroy(slam_ctx* ctx);
 int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream);
 int slam_hip_synchronize(slam_ctx* ctx);
 /* LDS bytes each search job (one wavefront) may use: a multiple of 1024 in [4096, 64512], default
- * 10240 (16 jobs then share a CU's 160 KB, as many as the kernels' registers allow; line walks: 12288,
- * 12 per CU).  Less LDS never
+ * 9216 (16 jobs then share a CU's 160 KB with room for their static LDS, as many as the kernels'
+ * registers allow; line walks: 12288, 12 per CU).  Less LDS never
  * adds jobs per CU; more LDS cuts large templates into fewer chunks at the price of fewer jobs per CU.
  * Results do not depend on it. */
 int slam_hip_set_match_lds(slam_ctx* ctx, int bytes);
