@@ -552,7 +552,16 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
     STAMP(4);
     bool first = true, refine = false;
     int nblocks = 0, yb = 0, xb = -o;
+    // The split travels through the block loop as one scalar (both sizes are multiples of 16 below 64 KB); it is
+    // unpacked per block, which keeps three wave-uniform values out of the registers that live across a block.
+    unsigned split = (unsigned)(lq.acc_bytes >> 4) | ((unsigned)(lq.tmpl_bytes >> 4) << 16);
     while (true) {
+        asm volatile("" : "+v"(split));
+        split = __builtin_amdgcn_readfirstlane(split);
+        LdsPlan lb;
+        lb.acc_bytes = (int)(split & 0xffffu) << 4;
+        lb.tmpl_bytes = (int)(split >> 16) << 4;
+        lb.tile_bytes = (lp.acc_bytes + lp.tmpl_bytes + lp.tile_bytes - lb.acc_bytes - lb.tmpl_bytes) & ~15;
         BlockArgs ba;
         if (!refine) {
             if (yb >= g.ah) {                              // scan finished: the argmax is known
@@ -583,7 +592,7 @@ __device__ __forceinline__ void fast_search(const Geo& g, const Tmpl& t, float* 
         const int URb = refine ? max(1, min(UR, TR - ba.bh + 1)) : UR;     // the 3-row refine block must fit the tile
         const int S = pick_slices(ba.strips * ba.bh, URb);
         STAMP(5);
-        fast_block(g, t, refine ? nullptr : scores, lds, lq, ba, URb, S, G, big, first, !refine, spfull, nm, best STAMP_PASS);
+        fast_block(g, t, refine ? nullptr : scores, lds, lb, ba, URb, S, G, big, first, !refine, spfull, nm, best STAMP_PASS);
         first = false;
         nblocks++;
         fs.ba = ba;
