@@ -121,7 +121,7 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
     if (!(refine_always || (double)b.v < refine_below)) return o;
 
     // the four neighbours of the peak: lanes 0..3 each fetch one
-    const int n = threadIdx.x & 3;
+    const int n = lane_here() & 3;
     const int nx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0);
     const int ny = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
     const bool in = nx >= 0 && ny >= 0 && nx < g.aw && ny < g.ah;

@@ -42,6 +42,15 @@ __device__ __forceinline__ void slam_stamp(int& slot, int id) {
 
 namespace slamdev {
 
+// The lane index as a value the optimiser cannot see through: what a phase derives from it (LDS addresses, float
+// copies, neighbour offsets) is then computed inside that phase instead of being hoisted out of the level loop of a
+// walk into registers that stay live, and spill, across all of it.
+__device__ __forceinline__ int lane_here() {
+    int l = (int)threadIdx.x;
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
 // ---- score formulas -------------------------------------------------------------------------
 // Exact integer sums in, IEEE single/double operations out; every operation is one correctly
 // rounded step, in the order of matching.cpp:70-72 (float cc, i2, p2; cc / (i2*p2)).

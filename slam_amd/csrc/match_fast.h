@@ -164,7 +164,7 @@ struct Walk2D {
 
 __device__ __forceinline__ Walk2D make_walk(int width, int rows) {
     Walk2D w;
-    const int lane = threadIdx.x;
+    const int lane = lane_here();
     if (width <= SLAM_WG) {
         const float rw = __builtin_amdgcn_rcpf((float)width);
         const int per = (int)(64.5f * rw);                               // rows handled per pass
@@ -186,7 +186,7 @@ __device__ __forceinline__ Walk2D make_walk(int width, int rows) {
 // to other lanes: the caller synchronises.
 __device__ __forceinline__ void stage_template(const Geo& g, const Tmpl& t, lds_u64* tmpl, lds_u64* taps_region, int taps_bytes,
                                                int u0, int ur, int G, unsigned long long& sp_part STAMP_ARG) {
-    const int lane = threadIdx.x;
+    const int lane = lane_here();
     {
     // ---- stage the template chunk: {P0, mask} per 4-pixel group -----------------------------
     const int ntap = G * 4 + ur;                       // column taps then row taps, 8 bytes each
@@ -642,7 +642,7 @@ __device__ __forceinline__ float subpixel_axis(float s, float a, float b, bool o
 
 __device__ __forceinline__ CoreOut mini_level(const Geo& g, const Tmpl& t, lds_u8* lds, const MiniPlan& mp,
                                               bool refine_always, double refine_below STAMP_ARG) {
-    const int lane = threadIdx.x;
+    const int lane = lane_here();
     const int G = mp.G, tp = mp.tp;
     lds_u64* tmpl = reinterpret_cast<lds_u64*>(lds);
     lds_u32* tile = reinterpret_cast<lds_u32*>(lds + g.ph * G * 8);
