@@ -3,11 +3,14 @@
 // hipcc --offload-arch=gfx950 -O3 valu_rate2.hip -o valu_rate2.bin && ./valu_rate2.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <vector>
+#include <algorithm>
 
 #define DEF_KERNEL(NAME, ASM)                                                                  \
-    __global__ void NAME(unsigned* out, int iters) {                                           \
+    __global__ void NAME(unsigned* out, int iters, unsigned long long* clk) {                  \
         unsigned a[8], b = threadIdx.x * 2654435761u + 1, c = blockIdx.x + 12345;              \
         for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;                                    \
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();                            \
         for (int it = 0; it < iters; it++) {                                                   \
             _Pragma("unroll") for (int r = 0; r < 8; r++) {                                    \
                 _Pragma("unroll") for (int i = 0; i < 8; i++)                                  \
@@ -16,6 +19,8 @@
         }                                                                                      \
         unsigned s = 0;                                                                        \
         for (int i = 0; i < 8; i++) s += a[i];                                                 \
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();                            \
+        if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;       \
         out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                        \
     }
 
@@ -44,29 +49,39 @@ DEF_KERNEL(k_lshlrev, "v_lshlrev_b32 %0, 3, %0")
 DEF_KERNEL(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0")
 
 template <typename K>
-void run(const char* name, K kern, unsigned* d, int waves_per_simd) {
+void run(const char* name, K kern, unsigned* d, unsigned long long* clk, int waves_per_simd) {
     const int iters = 4000;
     const int blocks = 256 * waves_per_simd;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    kern<<<blocks, 256>>>(d, iters);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    kern<<<blocks, 256>>>(d, iters, clk);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    kern<<<blocks, 256>>>(d, iters);
+    kern<<<blocks, 256>>>(d, iters, clk);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double insts = (double)blocks * 4 * iters * 64;
     const double per_simd_per_s = insts / (256.0 * 4) / (ms * 1e-3);
-    printf("%-22s waves/SIMD=%d  %.3f ms  %.2f cycles/inst per SIMD at 2.4 GHz\n", name, waves_per_simd, ms, 2.4e9 / per_simd_per_s);
+    // in-kernel shader clocks (s_memtime) per wave: with w co-resident waves per SIMD a wave's stream of
+    // iters*64 instructions takes w times the SIMD's cycles per instruction
+    std::vector<unsigned long long> h(blocks * 4);
+    (void)hipMemcpy(h.data(), clk, h.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double med = (double)h[h.size() / 2];
+    const double cyc = med / ((double)iters * 64) / waves_per_simd;
+    printf("%-22s waves/SIMD=%d  %.3f ms  %.2f cycles/inst per SIMD by s_memtime (clock %.2f GHz; %.2f if the clock were 2.4 GHz)\n",
+           name, waves_per_simd, ms, cyc, med / (ms * 1e-3) / 1e9, 2.4e9 / per_simd_per_s);
 }
 
 int main() {
     unsigned* d;
     (void)hipMalloc(&d, 256 * 8 * 256 * 4);
-    for (int w : {1, 4}) {
-#define RUN(K) run(#K, K, d, w)
+    unsigned long long* clk;
+    (void)hipMalloc(&clk, 256 * 8 * 4 * 8);
+    for (int w : {1, 2, 4, 8}) {
+#define RUN(K) run(#K, K, d, clk, w)
         RUN(k_add); RUN(k_max); RUN(k_max3); RUN(k_max_sdwa); RUN(k_pk_max); RUN(k_pk_add); RUN(k_pk_sub_clamp); RUN(k_perm);
         RUN(k_alignbyte); RUN(k_alignbit); RUN(k_bfe); RUN(k_and); RUN(k_and_or); RUN(k_lshl_or); RUN(k_bfi); RUN(k_dot4);
         RUN(k_dot2_u16); RUN(k_sad_u8); RUN(k_mad_u24); RUN(k_mul_lo); RUN(k_cndmask); RUN(k_lshlrev); RUN(k_mbcnt);

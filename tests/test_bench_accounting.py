@@ -27,7 +27,8 @@ def test_counted_cells_are_the_cells_the_search_visits(oracle):
     """One interior feature of the bench workload: the oracle's score maps (cells other than -1 are visited) hold
     exactly the counted number of cells at every level."""
     rng = np.random.default_rng(1)
-    frames, jobs, blob, truth = bench.build_workload(1, 123, rng)
+    frames, jobs, blob, truth = bench.build_time_steps(1, 1, 123, rng)
+    frames, jobs = frames[0], jobs[0]
     levels = oracle.pyramid(frames[0], bench.SUBS)
     lv = {l["level"]: l for l in bench.level_cells_and_bytes()}
     j = jobs[NFEAT_MID]
@@ -49,3 +50,22 @@ def test_counted_cells_are_the_cells_the_search_visits(oracle):
 
 
 NFEAT_MID = 27      # a feature away from the image border
+
+
+def test_time_steps_share_templates_and_know_their_truth():
+    """Two sequences, three time-steps: every time-step reuses the sequence's templates, frames differ by the
+    integer shift the truth records, and the job's prediction lies within 4 pixels of it."""
+    rng = np.random.default_rng(5)
+    frames, jobs, blob, truth = bench.build_time_steps(2, 3, 77, rng)
+    assert frames.shape == (3, 2, bench.H, bench.W) and len(jobs) == 3
+    for t in range(3):
+        j = jobs[t]
+        assert len(j) == 2 * bench.NFEAT and set(j["frame"]) == {0, 1}
+        assert np.array_equal(j["proj_off"], jobs[0]["proj_off"]) and np.array_equal(j["mask_off"], jobs[0]["mask_off"])
+        assert (np.abs(j["px"] - truth[t][:, 0]) < 4).all() and (np.abs(j["py"] - truth[t][:, 1]) < 4).all()
+        # the template of a feature is the frame content around its true position
+        k = bench.NFEAT + NFEAT_MID
+        ts = bench.TSIZE
+        tx, ty = truth[t][k]
+        cut = frames[t, 1][ty - ts // 2:ty + ts // 2 + 1, tx - ts // 2:tx + ts // 2 + 1]
+        assert np.array_equal(cut.reshape(-1), blob[j["proj_off"][k]:j["proj_off"][k] + ts * ts])
