@@ -626,6 +626,8 @@ def main(argv=None):
         step(t)
     torch.cuda.synchronize()
     res = [d.cpu().numpy().view(TRACK_RES_DT) for d in d_out]
+    deferred = C.c_int32(0)
+    capi.check(ctx.handle, L.slam_hip_debug_walk_deferred(ctx.handle, C.byref(deferred)))
     for r in res:
         assert (r["status"] == 0).all(), "device rejected jobs"
     lc = level_cells_and_bytes()
@@ -721,9 +723,10 @@ def main(argv=None):
                        "frames_per_s": nseq * world * args.steps / elapsed, "tracked_fraction": tracked, "h2d_in_step": bool(args.with_h2d),
                        "parity": None if args.no_cpu else "every rank compared a sample of each time-step's results with the oracle bit for bit",
                        "parallelism": "sequences sharded over %d GPU(s), no collective on the data path" % world},
-            "roofline": {"bound": "hbm", "kernel": "track_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "track_lean_kernel+track_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_rate": ach / HBM_COPY_GBS, "traffic": tr,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms, "jobs_per_launch": njobs,
+                         "jobs_left_to_general_kernel": deferred.value,
                          "u8_mac_per_s": macs / (kern_ms * 1e-3),
                          "frac_of_packed_dot_peak": macs / (kern_ms * 1e-3) / DOT4_PEAK_MEASURED,
                          "frac_of_nominal_dot_peak": macs / (kern_ms * 1e-3) / DOT4_PEAK_NOMINAL,

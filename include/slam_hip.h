@@ -405,6 +405,12 @@ int slam_hip_debug_score_formulas(slam_ctx* ctx, const uint64_t* cc, const uint6
 /* cv::resize(src, dst, Size(dw, dh)) (INTER_LINEAR) of one host image on the device. */
 int slam_hip_debug_resize(slam_ctx* ctx, const uint8_t* src, int sw, int sh, size_t spitch,
                           uint8_t* dst, int dw, int dh, size_t dpitch);
+/* Point walks (slam_hip_track_batch[_d] and the entry points built on it) run in two kernels: a lean one for walks
+ * whose every level is an interior window that fits one job's LDS, and the general one for the jobs the first leaves
+ * over.  After the stream has drained, *out_deferred = how many jobs of the context's last walk batch took the
+ * general kernel (0 when the lean kernel is switched off by SLAM_HIP_NO_LEAN=1 or SLAM_HIP_FORCE_DIRECT=1).
+ * Synchronises the stream. */
+int slam_hip_debug_walk_deferred(slam_ctx* ctx, int* out_deferred);
 /* Library build identification: "slam_hip <version> gfx950". */
 const char* slam_hip_version(void);
 

@@ -25,7 +25,8 @@ def main():
         bench.THRESHOLD = -10.0                         # never stops early
         nframes = 128 if bench.TSIZE > 40 else 512
     rng = np.random.default_rng(5)
-    frames, jobs, blob, truth = bench.build_workload(nframes, 77, rng)
+    frames, jobs, blob, truth = bench.build_time_steps(nframes, 1, 77, rng)
+    frames, jobs = frames[0], jobs[0]
     dev = torch.device("cuda", 0)
     d_frames = torch.from_numpy(frames).to(dev)
     d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)

@@ -45,6 +45,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     c->stream = c->own_stream;
     const char* fd = getenv("SLAM_HIP_FORCE_DIRECT");
     c->force_direct = (fd && fd[0] == '1') ? 1 : 0;
+    const char* nl = getenv("SLAM_HIP_NO_LEAN");
+    c->no_lean = (nl && nl[0] == '1') ? 1 : 0;
     const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");
     if (lk && atoi(lk) >= 4 && atoi(lk) <= 63) c->match_lds_bytes = c->line_lds_bytes = atoi(lk) * 1024;
     *out = c;
@@ -57,6 +59,7 @@ extern "C" int slam_hip_destroy(slam_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 4; i++)
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+    if (ctx->d_queue) (void)hipFree(ctx->d_queue);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SLAM_HIP_OK;
@@ -136,6 +139,21 @@ int slam_stage_reserve(slam_ctx* ctx, int slot, size_t bytes) {
         return slam_set_error(ctx, SLAM_HIP_ENOMEM, "staging hipMalloc(%zu): %s", want, hipGetErrorString(e));
     }
     ctx->stage_bytes[slot] = want;
+    return SLAM_HIP_OK;
+}
+
+// The deferred-job queue of the walk kernels holds a counter block and one word per job of the largest batch seen.
+int slam_queue_reserve(slam_ctx* ctx, int njobs) {
+    if ((size_t)njobs <= ctx->queue_jobs) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_queue) { SLAM_HIP_CHECK(ctx, hipFree(ctx->d_queue)); ctx->d_queue = nullptr; ctx->queue_jobs = 0; }
+    const size_t want = (size_t)njobs + (size_t)njobs / 2 + 65536;
+    hipError_t e = hipMalloc((void**)&ctx->d_queue, (want + 16) * sizeof(int));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return slam_set_error(ctx, SLAM_HIP_ENOMEM, "walk queue hipMalloc(%zu words): %s", want + 16, hipGetErrorString(e));
+    }
+    ctx->queue_jobs = want;
     return SLAM_HIP_OK;
 }
 

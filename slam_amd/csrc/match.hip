@@ -6,7 +6,7 @@
 #include <cfloat>
 #include <climits>
 
-#include "match_fast.h"
+#include "match_lean.h"
 
 using namespace slamdev;
 
@@ -158,21 +158,6 @@ __device__ __forceinline__ CoreOut match_core(const Geo& g, const Tmpl& t, float
     return o;
 }
 
-// (int)round((double)f) for a float f: C round() (half away from zero) of the same real value; the float is
-// split exactly into trunc and fraction, so single precision gives the identical integer.
-__device__ __forceinline__ int round_f2i(float f) {
-    const float tr = truncf(f);
-    const float fr = __fsub_rn(f, tr);                    // exact: |fr| < 1 and tr share f's exponent range
-    return (int)tr + (fr >= 0.5f ? 1 : 0) - (fr <= -0.5f ? 1 : 0);
-}
-
-// value of lane `i` (wave-uniform index)
-// per-level constants of a point walk, one LDS entry per pyramid level
-struct TrackLevel { float sub, rad; int lw, lh, tw, th, rs, pad; long long lp, ls, ld; double scx, scy; };
-
-// a value every lane holds alike, moved to scalar registers
-__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float uni_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ long long uni_i64(long long v) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
@@ -187,10 +172,6 @@ __device__ __forceinline__ long long lane_i64(long long v, int i) {
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ double lane_f64(double v, int i) { return __longlong_as_double(lane_i64(__double_as_longlong(v), i)); }
-
-__device__ __forceinline__ bool span_ok(long long off, long long len, unsigned long long total) {
-    return off >= 0 && len >= 0 && (unsigned long long)off <= total && (unsigned long long)len <= total - (unsigned long long)off;
-}
 
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
@@ -246,15 +227,15 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
     if (threadIdx.x == 0) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
 }
 
-__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
-                                                        int njobs, const uint8_t* __restrict__ blob,
-                                                        unsigned long long blob_bytes,
-                                                        slam_track_result* __restrict__ out, int force_direct, int lds_total) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    lds_u8* lds = (lds_u8*)dyn_lds;
-    const LdsPlan plan = make_lds_plan(lds_total);
-    const int j = blockIdx.x;
-    if (j >= njobs) return;
+// per-level constants of a point walk, one LDS entry per pyramid level
+struct TrackLevel { float sub, rad; int lw, lh, tw, th, rs, pad; long long lp, ls, ld; double scx, scy; };
+
+// The level loop of SLAM::Feature::track (feature.cpp:117-172) for job j, general form: any window, any template
+// size the tiled core or direct evaluation can take.
+__device__ __forceinline__ void track_job(const slam_pyr_dev& pyr, const slam_track_job* __restrict__ jobs, int j,
+                                          const uint8_t* __restrict__ blob, unsigned long long blob_bytes,
+                                          slam_track_result* __restrict__ out, int force_direct, lds_u8* lds,
+                                          const LdsPlan& plan, TrackLevel* lc) {
     const slam_track_job job = jobs[j];
     const int tid = threadIdx.x;
     if (job.projw <= 0 || job.projh <= 0) {   // feature.cpp:112-115
@@ -286,7 +267,6 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
     // Per-level constants do not depend on the walk's results: lane l computes those of level l once
     // (template size and cv::resize scales, search radius, window size) and parks them in LDS; the level
     // loop reads entry i back into scalar registers.
-    __shared__ TrackLevel lc[SLAM_HIP_MAX_LEVELS];
     if (tid < pyr.nlev) {
         TrackLevel c;
         float subn = 1.f;
@@ -369,6 +349,131 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         else { r.x = (int)tx; r.y = (int)ty; r.response = response; r.dx = sdx; r.dy = sdy; r.levels_run = levels_run; }
         r.status = SLAM_HIP_OK;
         out[j] = r;
+    }
+}
+
+// Queue of jobs the lean kernel left to the general one: word 0 counts them, the job indices start at word 16.
+#define SLAM_DEFER_LIST 16
+
+// General walk kernel.  queue == nullptr: workgroup b walks job b.  Otherwise the workgroups share out the jobs the
+// lean kernel queued (a later launch on the same stream: its counter and list are complete and visible).
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_bytes,
+                                                        slam_track_result* __restrict__ out, int force_direct, int lds_total,
+                                                        const int* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    __shared__ TrackLevel lc[SLAM_HIP_MAX_LEVELS];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const LdsPlan plan = make_lds_plan(lds_total);
+    if (!queue) {
+        const int j = blockIdx.x;
+        if (j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
+        return;
+    }
+    const int count = min(queue[0], njobs);
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const int j = queue[SLAM_DEFER_LIST + q];
+        __syncthreads();                                   // the previous job's last readers of lc and the dynamic LDS
+        if (j >= 0 && j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
+    }
+}
+
+// Lean walk kernel: the level loop of SLAM::Feature::track (feature.cpp:117-172) for walks whose every level is an
+// interior window small enough for lean_level (match_lean.h).  A job it does not cover - checked level by level, as
+// the windows depend on the results - is appended to the queue and walked again from the start by track_kernel;
+// nothing is written to `out` for it here.
+__device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_track_job& job, const uint8_t* __restrict__ blob,
+                                          unsigned long long blob_bytes, lds_u8* lds, int lds_total, slam_track_result& r) {
+    STAMP_DECL;
+    STAMP(1);
+    const long long pbytes = (long long)job.projw * job.projh;
+    bool ok = job.projw >= 1 && job.projh >= 1 && job.projw <= 255 && job.projh <= 255 &&
+              job.frame >= 0 && job.frame < pyr.nframes && job.stride >= 1 && job.stride <= 1024 &&
+              span_ok(job.proj_off, pbytes, blob_bytes) && span_ok(job.mask_off, pbytes, blob_bytes) &&
+              fabsf(job.px) < 1e7f && fabsf(job.py) < 1e7f && job.threshold == job.threshold;
+    const bool coarse_area = (job.flags & SLAM_HIP_TRACK_COARSE_AREA) != 0;
+    if (coarse_area)
+        ok = ok && job.aw >= 1 && job.ah >= 1 && job.aw <= 255 && job.ah <= 255 &&
+             job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28) &&
+             (job.amask_off == -1 || span_ok(job.amask_off, (long long)job.aw * job.ah, blob_bytes));
+    if (!ok) { LEAN_REJECT(10); return false; }
+    LeanLevel L;
+    L.patch = blob + job.proj_off; L.mask = blob + job.mask_off; L.limit = blob + blob_bytes;
+    L.srcw = job.projw; L.srch = job.projh;
+    const double stop_below = __dmul_rn(0.67, (double)job.threshold);           // feature.cpp:151
+    float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
+    float response = 0.f, sdx = 0.f, sdy = 0.f;
+    int levels_run = 0;
+    const int nlev = pyr.nlev;
+    for (int i = nlev - 1; i >= 0; --i) {
+        STAMP_LEVEL(i);
+        STAMP(2);
+        const slam_level_dev& lv = pyr.lev[i];
+        const float sub = lv.sub;
+        const bool p2 = lv.pow2 != 0;           // dividing by a power of two and multiplying by its inverse are both exact
+        L.tw = job.projw; L.th = job.projh;     // feature.cpp:126-128
+        L.resized = sub != 1.f;
+        L.scx = 1.0; L.scy = 1.0;
+        if (L.resized) {                        // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
+            L.tw = uni_i32((int)(p2 ? __fmul_rn((float)job.projw, lv.inv_sub) : __fdiv_rn((float)job.projw, sub)));
+            L.th = uni_i32((int)(p2 ? __fmul_rn((float)job.projh, lv.inv_sub) : __fdiv_rn((float)job.projh, sub)));
+            if (L.tw <= 0 || L.th <= 0) { LEAN_REJECT(11); return false; }
+            L.scx = resize_scale(job.projw, L.tw);
+            L.scy = resize_scale(job.projh, L.th);
+        }
+        float rad = lv.rad;                     // feature.cpp:134 (coarsest) or :136 (finer)
+        if (i == 0 && nlev > 1) rad = __fmul_rn(rad, (float)job.stride);        // feature.cpp:137-138
+        const int rs = uni_i32(round_f2i(__fadd_rn(__fmul_rn(2.f, rad), 1.f)));  // feature.cpp:146
+        // feature.cpp:144-146
+        const float qx = p2 ? __fmul_rn(tx, lv.inv_sub) : __fdiv_rn(tx, sub), qy = p2 ? __fmul_rn(ty, lv.inv_sub) : __fdiv_rn(ty, sub);
+        int rx = uni_i32(round_f2i(__fsub_rn(qx, rad))), ry = uni_i32(round_f2i(__fsub_rn(qy, rad)));
+        int rw = rs, rh = rs;
+        L.amask = nullptr;
+        if (coarse_area && i == nlev - 1) {     // caller's window and area mask on the coarsest level
+            rx = job.ax; ry = job.ay; rw = job.aw; rh = job.ah;
+            if (job.amask_off != -1) L.amask = blob + job.amask_off;
+        }
+        L.im = lv.data + (long long)job.frame * lv.frame_stride;
+        L.ipitch = (unsigned)lv.pitch; L.w = lv.w; L.h = lv.h;
+        L.x0 = rx - L.tw / 2; L.y0 = ry - L.th / 2;                                // matching.cpp:38-39
+        L.aw = rw; L.ah = rh;
+        L.step = (i == 0) ? 1 : job.stride;                                         // feature.cpp:147-149
+        // every candidate patch inside the image (no crop, no border cells: matching.cpp:19-25,44-49), and image rows
+        // that can be fetched as aligned dwords
+        if (rw < 1 || rh < 1 || rw > 255 || rh > 255 || L.x0 < 0 || L.y0 < 0 || L.x0 + rw + L.tw - 1 > L.w || L.y0 + rh + L.th - 1 > L.h ||
+            lv.pitch > 0x7fffffffLL || ((reinterpret_cast<unsigned long long>(L.im) | (unsigned long long)lv.pitch) & 3ull) != 0) {
+            LEAN_REJECT(12 + 1000 * i); return false;
+        }
+        // feature.cpp:151-152: the level that ends the walk also reports the sub-pixel fit
+        const LeanOut o = lean_level(L, lds, lds_total, i == 0, stop_below STAMP_PASS);
+        if (!o.ok) return false;
+        levels_run++;
+        response = o.response; sdx = o.dx; sdy = o.dy;
+        tx = __fmul_rn((float)o.x, sub);         // feature.cpp:150
+        ty = __fmul_rn((float)o.y, sub);
+        if ((double)response < stop_below) break;   // feature.cpp:151-152
+    }
+    STAMP(30);
+    r.x = (int)tx; r.y = (int)ty; r.response = response; r.dx = sdx; r.dy = sdy; r.levels_run = levels_run;
+    r.status = SLAM_HIP_OK;
+    return true;
+}
+
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_bytes,
+                                                        slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_track_job job = jobs[j];
+    slam_track_result r;
+    const bool done = lean_walk(pyr, job, blob, blob_bytes, lds, lds_total, r);
+    if (threadIdx.x == 0) {
+        if (done) out[j] = r;
+        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
     }
 }
 
@@ -601,9 +706,31 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
+    if (ctx->force_direct || ctx->no_lean) {               // diagnostic settings: every job through the general kernel
+        hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
+                           ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
+                           ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
+        SLAM_HIP_CHECK(ctx, hipGetLastError());
+        return SLAM_HIP_OK;
+    }
+    int rc2 = slam_queue_reserve(ctx, njobs);
+    if (rc2 != SLAM_HIP_OK) return rc2;
+    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, ctx->d_queue);
+}
+
+// Lean kernel over all jobs, then the general kernel over whatever it queued.  `queue`: device words, SLAM_DEFER_LIST
+// + njobs of them.  Allocates nothing.
+int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
+                      size_t blob_bytes, slam_track_result* d_out, int* queue) {
+    SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(track_lean_kernel, dim3(njobs), dim3(SLAM_WG), ctx->lean_lds_bytes, ctx->stream, pyr->dev, d_jobs, njobs,
+                       d_blob, (unsigned long long)blob_bytes, d_out, ctx->lean_lds_bytes, queue);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    // enough workgroups to fill the chip if everything was queued, few enough to start and end in microseconds if nothing was
+    const int grid = njobs < 4096 ? njobs : 4096;
+    hipLaunchKernelGGL(track_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                       ctx->force_direct, ctx->match_lds_bytes);
+                       0, ctx->match_lds_bytes, (const int*)queue);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }
@@ -675,6 +802,16 @@ extern "C" int slam_hip_line_track_batch(slam_ctx* ctx, const slam_pyr* pyr, con
     if (rc != SLAM_HIP_OK) return rc;
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_stage[2], rb, hipMemcpyDeviceToHost, ctx->stream));
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_debug_walk_deferred(slam_ctx* ctx, int* out_deferred) {
+    if (!ctx || !out_deferred) return SLAM_HIP_EINVAL;
+    *out_deferred = 0;
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_queue || ctx->force_direct || ctx->no_lean) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipMemcpy(out_deferred, ctx->d_queue, sizeof(int), hipMemcpyDeviceToHost));
     return SLAM_HIP_OK;
 }
 

@@ -26,18 +26,24 @@ __device__ __forceinline__ void slam_stamp(int& slot, int id) {
 #define STAMP_DECL int stamp_slot = 0
 #define STAMP_ARG , int& stamp_slot
 #define STAMP_PASS , stamp_slot
+#define STAMP_LEVEL(i) ((void)0)
 #elif defined(SLAM_DIAG_EXIT_AT)
-// diagnostic builds that end every wave at one phase boundary: the instruction counters of such a build, minus
-// those of the build that ends one boundary earlier, are the cost of the phase in between (never shipped)
-#define STAMP(id) do { if ((id) == SLAM_DIAG_EXIT_AT) __builtin_amdgcn_endpgm(); } while (0)
-#define STAMP_DECL ((void)0)
-#define STAMP_ARG
-#define STAMP_PASS
+// diagnostic builds that end every wave at one phase boundary of one pyramid level: the instruction counters of such
+// a build, minus those of the build that ends one boundary earlier, are the cost of the phase in between (never shipped)
+#ifndef SLAM_DIAG_EXIT_LEVEL
+#define SLAM_DIAG_EXIT_LEVEL -1
+#endif
+#define STAMP(id) do { if ((id) == SLAM_DIAG_EXIT_AT && diag_lvl == SLAM_DIAG_EXIT_LEVEL) __builtin_amdgcn_endpgm(); } while (0)
+#define STAMP_DECL int diag_lvl = -1
+#define STAMP_ARG , int diag_lvl
+#define STAMP_PASS , diag_lvl
+#define STAMP_LEVEL(i) diag_lvl = (i)
 #else
 #define STAMP(id) ((void)0)
 #define STAMP_DECL ((void)0)
 #define STAMP_ARG
 #define STAMP_PASS
+#define STAMP_LEVEL(i) ((void)0)
 #endif
 
 namespace slamdev {

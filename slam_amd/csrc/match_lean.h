@@ -1,0 +1,406 @@
+// Lean search of one pyramid level for the point walk (SLAM::Feature::track, feature.cpp:124-152): the common case
+// in which every candidate patch of the window lies inside the image, the template is small and the whole score
+// map fits one job's LDS at once.  Same integer sums, same formulas and the same argmax rule as the general core
+// (match_fast.h); what differs is the data layout, chosen so that the inner loop is nearly nothing but v_dot4:
+//
+//   tile   : the image rows under all cells, one 16-byte entry per dword position p of a row holding the four byte
+//            windows that start at bytes 4p, 4p+1, 4p+2, 4p+3 - the shifts are paid once per tile, not per
+//            (cell, template group), and a strip of 4 adjacent cells gets its 4 windows with one ds_read_b128
+//   lists  : the template's 4-pixel groups as a list of {P0 = patch*mask, tile offset} entries; groups whose mask is
+//            all zero are dropped, groups that keep all four pixels come first (their window needs no masking before
+//            its energy is summed), the others follow with their mask in a parallel array.  Both parts are padded to
+//            a multiple of the slice count, so every lane runs the same trip counts
+//   acc    : {CC, SI} per cell, u32, LDS atomics
+//
+// A lane owns a unit (a strip of 4 adjacent cells at stride 1, one cell on a coarser lattice) and one of S slices of
+// the entry lists.  Anything this path does not cover is left to the general kernel: the caller defers the job.
+#pragma once
+
+#include "match_fast.h"
+
+namespace slamdev {
+
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4u32 lds_v4u32;
+
+// (int)round((double)f) for a float f: C round() (half away from zero) of the same real value; the float is
+// split exactly into trunc and fraction, so single precision gives the identical integer.
+__device__ __forceinline__ int round_f2i(float f) {
+    const float tr = truncf(f);
+    const float fr = __fsub_rn(f, tr);                    // exact: |fr| < 1 and tr share f's exponent range
+    return (int)tr + (fr >= 0.5f ? 1 : 0) - (fr <= -0.5f ? 1 : 0);
+}
+
+__device__ __forceinline__ bool span_ok(long long off, long long len, unsigned long long total) {
+    return off >= 0 && len >= 0 && (unsigned long long)off <= total && (unsigned long long)len <= total - (unsigned long long)off;
+}
+
+// a value every lane holds alike, moved to scalar registers
+__device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+struct LeanLevel {           // wave-uniform description of one level's search
+    const uint8_t* im;       // level image of the job's frame (4-byte aligned, pitch a multiple of 4)
+    unsigned ipitch;
+    int w, h;
+    int tw, th;              // template size at this level
+    int x0, y0;              // image position of template pixel (0,0) for cell (0,0); the window is interior:
+    int aw, ah;              //   x0 >= 0, y0 >= 0, x0 + aw + tw - 1 <= w, y0 + ah + th - 1 <= h
+    int step;                // lattice step: cells (i*step, j*step) are visited (matching.cpp:64-66 with xl0 = yl0 = 0)
+    const uint8_t* amask;    // area mask (pitch aw) or nullptr: cells whose byte is 0 are not visited (matching.cpp:66)
+    const uint8_t* patch;    // full-resolution template and mask, pitch srcw
+    const uint8_t* mask;
+    const uint8_t* limit;    // end of the buffer they live in
+    int srcw, srch;
+    bool resized;            // template resized to (tw, th) on the fly (feature.cpp:130-131)
+    double scx, scy;
+};
+
+struct LeanOut { int x, y; float response, dx, dy; bool ok; };
+
+#define LEAN_MAX_S 16
+
+// diagnostic build (-DSLAM_LEAN_DEBUG): job 0 says why a walk was left to the general kernel
+#ifdef SLAM_LEAN_DEBUG
+#define LEAN_REJECT(code) do { if (blockIdx.x == 0 && threadIdx.x == 0) printf("lean reject %d\n", (code)); } while (0)
+#else
+#define LEAN_REJECT(code) ((void)0)
+#endif
+
+// Candidate slice counts; the cost model is instruction counts of the loops below.
+__device__ __forceinline__ int lean_pick_slices(int nunits, int nA, int nB, bool strips) {
+    const int ca = strips ? 9 : 4, cb = strips ? 14 : 6, cf = strips ? 30 : 16;
+    int best_s = 1, best_c = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        constexpr int cand[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+        const int s = cand[q];
+        const int passes = (nunits * s + SLAM_WG - 1) >> 6;
+        const int a = nA / s;
+        const int b = (nA - a * s + nB + s - 1) / s;
+        const int c = passes * (a * ca + b * cb + cf);
+        if (c < best_c) { best_c = c; best_s = s; }
+    }
+    return best_s;
+}
+
+// the F32 score (matching.cpp:70-72) of a cell from its sums; the caller has checked that the cell is visited
+__device__ __forceinline__ float lean_score(const lds_u32* acc, int ai, float p2f) {
+    return score_f32_n(acc[2 * ai], acc[2 * ai + 1], p2f);
+}
+
+// One entry of the lists for the NC cells of a unit: cc += <window, P0>, si += <window & M, window & M>.
+template <int NC, bool MASKED>
+__device__ __forceinline__ void lean_step(const lds_u8* wp, unsigned P0, unsigned M, unsigned (&cc)[NC], unsigned (&si)[NC]) {
+    if (NC == 4) {
+        const v4u32 w = *reinterpret_cast<const lds_v4u32*>(wp);
+        const unsigned w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
+        const unsigned m0 = MASKED ? (w0 & M) : w0, m1 = MASKED ? (w1 & M) : w1, m2 = MASKED ? (w2 & M) : w2, m3 = MASKED ? (w3 & M) : w3;
+        cc[0] = __builtin_amdgcn_udot4(w0, P0, cc[0], false); si[0] = __builtin_amdgcn_udot4(m0, m0, si[0], false);
+        cc[1 % NC] = __builtin_amdgcn_udot4(w1, P0, cc[1 % NC], false); si[1 % NC] = __builtin_amdgcn_udot4(m1, m1, si[1 % NC], false);
+        cc[2 % NC] = __builtin_amdgcn_udot4(w2, P0, cc[2 % NC], false); si[2 % NC] = __builtin_amdgcn_udot4(m2, m2, si[2 % NC], false);
+        cc[3 % NC] = __builtin_amdgcn_udot4(w3, P0, cc[3 % NC], false); si[3 % NC] = __builtin_amdgcn_udot4(m3, m3, si[3 % NC], false);
+    } else {
+        const unsigned w = *reinterpret_cast<const lds_u32*>(wp);
+        const unsigned m0 = MASKED ? (w & M) : w;
+        cc[0] = __builtin_amdgcn_udot4(w, P0, cc[0], false); si[0] = __builtin_amdgcn_udot4(m0, m0, si[0], false);
+    }
+}
+
+// Tasks are dealt slice-major (task = slice * nunits + unit): neighbouring lanes then hold neighbouring units of one
+// slice, so an entry read is one broadcast address and the window reads of a lane group fall on consecutive 16-byte
+// tile entries (distinct banks).  Entries are fetched four ahead of their use; the lists are padded so that reading
+// up to four entries past a slice stays inside them.
+template <int NC>
+__device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u64* list, const lds_u32* marr, lds_u32* acc,
+                                                int nunits, int S, int na, int nb, int nA1, int div_units, int tp, int o, int step) {
+    const int lane = lane_here();
+    const int ntask = nunits * S;
+    const float rnu = __builtin_amdgcn_rcpf((float)nunits), rdu = __builtin_amdgcn_rcpf((float)div_units);
+    for (int t0 = 0; t0 < ntask; t0 += SLAM_WG) {
+        const int task = min(t0 + lane, ntask - 1);        // surplus lanes repeat the last task and do not flush
+        const int slice = (int)(((float)task + 0.5f) * rnu), unit = task - slice * nunits;
+        const int uy = (int)(((float)unit + 0.5f) * rdu), ux = unit - uy * div_units;
+        unsigned tb;                                       // byte offset of the unit's first window in the tile
+        if (NC == 4) tb = (unsigned)(uy * tp + ux) * 16u;
+        else { const int bx = o + ux * step; tb = (unsigned)((uy * step) * tp + (bx >> 2)) * 16u + (unsigned)(bx & 3) * 4u; }
+        const lds_u8* tl = tile + tb;
+        unsigned cc[NC], si[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) { cc[k] = 0; si[k] = 0; }
+        {   // groups that keep all four pixels
+            const lds_u64* ea = list + slice * na;
+            unsigned long long q0 = ea[0], q1 = ea[1], q2 = ea[2], q3 = ea[3];
+            int e = 0;
+            for (; e + 4 <= na; e += 4) {
+                const unsigned long long c0 = q0, c1 = q1, c2 = q2, c3 = q3;
+                q0 = ea[e + 4]; q1 = ea[e + 5]; q2 = ea[e + 6]; q3 = ea[e + 7];
+                lean_step<NC, false>(tl + (unsigned)(c0 >> 32), (unsigned)c0, 0u, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c1 >> 32), (unsigned)c1, 0u, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c2 >> 32), (unsigned)c2, 0u, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c3 >> 32), (unsigned)c3, 0u, cc, si);
+            }
+            if (e < na) lean_step<NC, false>(tl + (unsigned)(q0 >> 32), (unsigned)q0, 0u, cc, si);
+            if (e + 1 < na) lean_step<NC, false>(tl + (unsigned)(q1 >> 32), (unsigned)q1, 0u, cc, si);
+            if (e + 2 < na) lean_step<NC, false>(tl + (unsigned)(q2 >> 32), (unsigned)q2, 0u, cc, si);
+        }
+        {   // partly masked groups (and the padding entries, mask 0)
+            const lds_u64* eb = list + nA1 + slice * nb;
+            const lds_u32* mb = marr + nA1 + slice * nb;
+            unsigned long long q0 = eb[0], q1 = eb[1];
+            unsigned m0 = mb[0], m1 = mb[1];
+            int e = 0;
+            for (; e + 2 <= nb; e += 2) {
+                const unsigned long long c0 = q0, c1 = q1;
+                const unsigned k0 = m0, k1 = m1;
+                q0 = eb[e + 2]; q1 = eb[e + 3]; m0 = mb[e + 2]; m1 = mb[e + 3];
+                lean_step<NC, true>(tl + (unsigned)(c0 >> 32), (unsigned)c0, k0, cc, si);
+                lean_step<NC, true>(tl + (unsigned)(c1 >> 32), (unsigned)c1, k1, cc, si);
+            }
+            if (e < nb) lean_step<NC, true>(tl + (unsigned)(q0 >> 32), (unsigned)q0, m0, cc, si);
+        }
+        if (t0 + lane < ntask) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                __hip_atomic_fetch_add(acc + (unit * NC + k) * 2, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + (unit * NC + k) * 2 + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
+// One level.  `refine`: also report the sub-pixel offset of the peak (the level that ends a walk does).
+// Returns ok = false when the level is not covered here (nothing has been written anywhere).
+__device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, int lds_total, bool refine_always, double refine_below STAMP_ARG) {
+    LeanOut out;
+    out.ok = false; out.x = 0; out.y = 0; out.response = 0.f; out.dx = 0.f; out.dy = 0.f;
+    const int lane = lane_here();
+    const int G = (L.tw + 3) >> 2, NG = L.th * G;
+    const int o = L.x0 & 3;
+    const bool strips = L.step == 1;
+    const int nx = strips ? L.aw : (L.aw + L.step - 1) / L.step, ny = strips ? L.ah : (L.ah + L.step - 1) / L.step;
+    const int cols = (o + L.aw + 3) >> 2;                  // dword columns that hold a cell's first pixel
+    const int tp = cols + G - 1;                           // window positions per tile row
+    const int trows = L.ah + L.th - 1;
+    const int nunits = strips ? cols * L.ah : nx * ny;
+    const int nacc = strips ? nunits * 4 : nunits;
+    const int cap = NG + LEAN_MAX_S + 8;                   // room for the padding entries and for reads a few entries ahead
+    const int tile_bytes = trows * tp * 16;
+    const int raw_bytes = NG * 8 + (L.resized ? (G * 4 + L.th) * 8 : 0);
+    const int acc_bytes = (nacc * 8 + 15) & ~15;
+    const int list_bytes = cap * 8, marr_bytes = (cap * 4 + 15) & ~15;
+    const int need = acc_bytes + list_bytes + marr_bytes + max(tile_bytes, raw_bytes);
+    // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
+    if (need > lds_total || L.tw > 256 || L.th > 256 || L.tw * L.th > 66051 || tp > 64 || nx * ny > 4096) { LEAN_REJECT(100 + need); return out; }
+    // tile rows are fetched as aligned dwords: a needed byte must not sit in a partial last dword of the image row
+    if (L.x0 + L.aw + L.tw - 1 > (L.w & ~3)) { LEAN_REJECT(2); return out; }
+    lds_u32* acc = reinterpret_cast<lds_u32*>(lds);
+    lds_u64* list = reinterpret_cast<lds_u64*>(lds + acc_bytes);
+    lds_u32* marr = reinterpret_cast<lds_u32*>(lds + acc_bytes + list_bytes);
+    lds_u8* tile = lds + acc_bytes + list_bytes + marr_bytes;
+    lds_u64* raw = reinterpret_cast<lds_u64*>(tile);       // {P0, M} per group in (row, group) order, until the tile is staged
+    lds_u64* taps = raw + NG;
+
+    STAMP(50);
+    __syncthreads();                                       // the previous level's readers of this LDS are done
+    for (int i = lane; i < nacc * 2; i += SLAM_WG) acc[i] = 0;
+
+    // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
+    unsigned sp_part = 0;
+    int nA = 0, nB = 0;
+    const float rG = __builtin_amdgcn_rcpf((float)G);
+    if (!L.resized) {
+        for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+            const int i = i0 + lane;
+            unsigned P0 = 0, M = 0;
+            if (i < NG) {
+                const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G;
+                const long long so = (long long)u * L.srcw + gq * 4;
+                const unsigned P = load4(L.patch + so, L.limit);
+                const unsigned Mraw = load4(L.mask + so, L.limit);
+                const int nb = min(4, L.tw - gq * 4);
+                const unsigned keep = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+                const unsigned nz = (((Mraw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | Mraw) & 0x80808080u;   // per byte: non-zero -> 0x80
+                M = ((nz >> 7) * 0xFFu) & keep;
+                P0 = P & M;
+                raw[i] = ((unsigned long long)M << 32) | P0;
+                sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
+            }
+            nA += __builtin_popcountll(__ballot(M == 0xFFFFFFFFu));
+            nB += __builtin_popcountll(__ballot(M != 0u && M != 0xFFFFFFFFu));
+        }
+    } else {
+        // cv::resize of template and mask on the fly (feature.cpp:130-131): tap tables first, then one pixel per lane
+        // and step - 4 source bytes of the patch, 4 of the mask, fixed-point blend - into the raw bytes
+        const int wpx = G * 4, ntap = wpx + L.th;
+        for (int i = lane; i < ntap; i += SLAM_WG) {
+            int so, c0, c1;
+            if (i < wpx) resize_tap(min(i, L.tw - 1), L.scx, L.srcw, true, so, c0, c1);
+            else resize_tap(i - wpx, L.scy, L.srch, false, so, c0, c1);
+            taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)so;
+        }
+        __syncthreads();
+        lds_u8* rb = reinterpret_cast<lds_u8*>(raw);
+        const float rw = __builtin_amdgcn_rcpf((float)wpx);
+        const int n = L.th * wpx;
+        constexpr int NB = 2;
+        for (int i0 = 0; i0 < n; i0 += NB * SLAM_WG) {
+            ResizeSrc spx[NB], smx[NB];
+            unsigned long long txq[NB], tyq[NB];
+            int eo[NB]; bool pad[NB], live[NB];
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int ii = i0 + q * SLAM_WG + lane;
+                live[q] = ii < n;
+                const int i = min(ii, n - 1);
+                const int u = (int)(((float)i + 0.5f) * rw), v = i - u * wpx;
+                txq[q] = taps[min(v, L.tw - 1)]; tyq[q] = taps[wpx + u];
+                pad[q] = v >= L.tw;
+                eo[q] = (u * G + (v >> 2)) * 8 + (v & 3);
+                smx[q] = resize_fetch(L.mask, L.srcw, L.srch, (int)(unsigned)txq[q], (int)(unsigned)tyq[q]);
+                spx[q] = resize_fetch(L.patch, L.srcw, L.srch, (int)(unsigned)txq[q], (int)(unsigned)tyq[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; q++) {
+                const int a0 = (short)(txq[q] >> 32), a1 = (short)(txq[q] >> 48), b0 = (short)(tyq[q] >> 32), b1 = (short)(tyq[q] >> 48);
+                unsigned m = (unsigned)(resize_blend(smx[q], a0, a1, b0, b1, true) != 0);
+                unsigned p = (unsigned)resize_blend(spx[q], a0, a1, b0, b1, false) * m;
+                if (pad[q]) { p = 0; m = 0; }
+                if (live[q]) {
+                    sp_part += p * p;
+                    rb[eo[q]] = (unsigned char)p;
+                    rb[eo[q] + 4] = m ? 0xFF : 0x00;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+            const int i = i0 + lane;
+            const unsigned M = i < NG ? (unsigned)(raw[i] >> 32) : 0u;
+            nA += __builtin_popcountll(__ballot(M == 0xFFFFFFFFu));
+            nB += __builtin_popcountll(__ballot(M != 0u && M != 0xFFFFFFFFu));
+        }
+    }
+    const unsigned spfull = wave_sum_u32(sp_part);
+    const Norms nm = make_norms(spfull);
+    STAMP(51);
+
+    // ---- entry lists --------------------------------------------------------------------------------------------
+    const int S = lean_pick_slices(nunits, nA, nB, strips);
+    const int na = nA / S, nA1 = na * S;                    // all-kept entries per slice; the rest of them joins the masked part
+    const int nb = (nA - nA1 + nB + S - 1) / S, nB1 = nb * S;
+    __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
+    {
+        int baseA = 0, baseB = nA;
+        for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+            const int i = i0 + lane;
+            unsigned P0 = 0, M = 0;
+            if (i < NG) { const unsigned long long r = raw[i]; P0 = (unsigned)r; M = (unsigned)(r >> 32); }
+            const bool isA = M == 0xFFFFFFFFu, isB = M != 0u && !isA;
+            const unsigned long long ba = __ballot(isA), bb = __ballot(isB);
+            const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G;
+            const unsigned long long en = ((unsigned long long)((unsigned)(u * tp + gq) * 16u) << 32) | P0;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            // the raw region is read above and the lists written below live in different LDS ranges
+            if (isA) { const int p = baseA + __builtin_popcountll(ba & below); list[p] = en; marr[p] = M; }
+            if (isB) { const int p = baseB + __builtin_popcountll(bb & below); list[p] = en; marr[p] = M; }
+            baseA += __builtin_popcountll(ba); baseB += __builtin_popcountll(bb);
+        }
+        for (int p = nA + nB + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p] = 0u; }   // padding: adds nothing
+    }
+    __syncthreads();                                        // raw and taps are dead: the tile goes over them
+    STAMP(52);
+
+    // ---- image tile: four byte windows per dword position ---------------------------------------------------------
+    {
+        const int lg = 32 - __builtin_clz((unsigned)tp);   // tp + 1 <= 2^lg lanes per row: the last one only feeds its dword
+        const int c = lane & ((1 << lg) - 1), lr = lane >> lg, rpp = SLAM_WG >> lg;
+        const unsigned dcol = (unsigned)((L.x0 - o) >> 2) + (unsigned)c;
+        const bool ok0 = c < tp && (int)(dcol * 4 + 4) <= L.w, ok1 = c < tp && (int)(dcol * 4 + 8) <= L.w;
+        const uint8_t* src = L.im + (unsigned long long)L.y0 * L.ipitch;
+        unsigned go = (unsigned)lr * L.ipitch + dcol * 4u;
+        unsigned to = (unsigned)(lr * tp + c) * 16u;
+        for (int r = lr; r < trows; r += rpp) {
+            unsigned d0 = 0, d1 = 0;
+            if (ok0) d0 = *reinterpret_cast<const unsigned*>(src + go);
+            if (ok1) d1 = *reinterpret_cast<const unsigned*>(src + go + 4);
+            if (c < tp) {
+                v4u32 wv;
+                wv.x = d0; wv.y = __builtin_amdgcn_alignbyte(d1, d0, 1); wv.z = __builtin_amdgcn_alignbyte(d1, d0, 2); wv.w = __builtin_amdgcn_alignbyte(d1, d0, 3);
+                *reinterpret_cast<lds_v4u32*>(tile + to) = wv;
+            }
+            go += (unsigned)rpp * L.ipitch; to += (unsigned)(rpp * tp) * 16u;
+        }
+    }
+    __syncthreads();
+    STAMP(53);
+
+    // ---- sums -------------------------------------------------------------------------------------------------------
+    if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, cols, tp, o, 1);
+    else lean_accumulate<1>(tile, list, marr, acc, nunits, S, na, nb, nA1, nx, tp, o, L.step);
+    __syncthreads();
+    STAMP(54);
+
+    // ---- scores and argmax (cv::minMaxLoc: first maximum in row-major order, NaN never wins) ---------------------------
+    const int ncell = nx * ny;
+    const float rnx = __builtin_amdgcn_rcpf((float)nx);
+    const int arow = strips ? cols * 4 : nx;               // accumulator pitch in cells
+    const bool prune = ncell > SLAM_WG && nm.tn > 0.0;
+    const float rn = __builtin_amdgcn_rcpf(nm.p2f);
+    float keep_from = -FLT_MAX;
+    if (prune) {
+        // single-precision estimates (relative error below 1e-6); only cells within 1e-5 of the largest can hold the
+        // maximum or tie with it, and only those are scored with the exact formula
+        float m = -FLT_MAX;
+        for (int i = lane; i < ncell; i += SLAM_WG) {
+            const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+            const int x = cx * L.step, y = cy * L.step;
+            if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+            const int ai = strips ? (y * arow + o + x) : i;
+            const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
+            if (SI != 0u) m = fmaxf(m, (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn);
+        }
+#pragma unroll
+        for (int d = 1; d < SLAM_WG; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+        keep_from = m - 1e-5f * fmaxf(m, 1.f);
+    }
+    Best b = {-FLT_MAX, INT_MAX};
+    for (int i = lane; i < ncell; i += SLAM_WG) {
+        const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+        const int x = cx * L.step, y = cy * L.step;
+        if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+        const int ai = strips ? (y * arow + o + x) : i;
+        if (prune) {
+            const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
+            if (SI == 0u || !((float)CC * __builtin_amdgcn_rsqf((float)SI) * rn >= keep_from)) continue;
+        }
+        best_update(b, lean_score(acc, ai, nm.p2f), (y << 16) | x);
+    }
+    b = best_wave(b);
+    const int bidx = uni_i32(b.idx);
+    const float bv = uni_f32(b.v);
+    STAMP(55);
+    // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is a
+    // -1 of the untouched score map or there is none at all: the general kernel knows those cases.
+    if (!(bv >= 0.f) || bidx == INT_MAX) { LEAN_REJECT(3); return out; }
+    const int lx = bidx & 0xffff, ly = bidx >> 16;
+    out.ok = true;
+    out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
+    out.response = bv;
+    if (!(refine_always || (double)bv < refine_below)) return out;
+    if (!strips) return out;                               // off the lattice the four neighbours are unvisited: no fit
+    // sub-pixel fit through the four neighbours of the peak: lanes 0..3 score one each
+    const int n = lane & 3;
+    const int qx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0), qy = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
+    const bool in = qx >= 0 && qy >= 0 && qx < L.aw && qy < L.ah;
+    float v = -1.f;
+    if (in && !(L.amask && L.amask[qy * L.aw + qx] == 0)) v = lean_score(acc, qy * arow + o + qx, nm.p2f);
+    const float sl = __shfl(v, 0, 64), sr = __shfl(v, 1, 64), su = __shfl(v, 2, 64), sd = __shfl(v, 3, 64);
+    const bool okl = __shfl((int)in, 0, 64) != 0, okr = __shfl((int)in, 1, 64) != 0;
+    const bool oku = __shfl((int)in, 2, 64) != 0, okd = __shfl((int)in, 3, 64) != 0;
+    out.dx = subpixel_axis(bv, sl, sr, okl, okr);
+    out.dy = subpixel_axis(bv, su, sd, oku, okd);
+    return out;
+}
+
+}  // namespace slamdev

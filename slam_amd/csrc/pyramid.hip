@@ -294,6 +294,14 @@ static void pyr_refresh_dev(slam_pyr* p) {
     for (int l = 0; l < p->nlev; l++) {
         slam_level_dev& d = p->dev.lev[l];
         d.w = p->lw[l]; d.h = p->lh[l]; d.sub = p->subs[l];
+        const float sub = p->subs[l];
+        int ex = 0;
+        d.pow2 = (std::frexp(sub, &ex) == 0.5f && ex > -20 && ex < 20) ? 1 : 0;
+        d.inv_sub = 1.f / sub;
+        // feature.cpp:119,134: fullResSearchRad / sub on the coarsest level; :136: 1.3 * sub[i+1] / sub[i] below it
+        // (a double expression stored to float)
+        if (l == p->nlev - 1) d.rad = 20.f / sub;
+        else d.rad = (float)((1.3 * (double)p->subs[l + 1]) / (double)sub);
         if (p->d_level[l]) {
             d.data = p->d_level[l]; d.pitch = (long long)p->lpitch[l]; d.frame_stride = (long long)p->lstride[l];
         } else {

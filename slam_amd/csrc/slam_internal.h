@@ -20,6 +20,11 @@ struct slam_ctx {
     int line_lds_bytes = 12 * 1024;    // the same for line walks: 12 jobs per CU (3 per SIMD), large descriptors
     int match_lds_bytes = 9 * 1024;    // LDS per search job: 16 jobs share a CU's 160 KB, as many as its registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
     int force_direct = 0;   // SLAM_HIP_FORCE_DIRECT=1: search by direct evaluation (cross-check of the tiled core)
+    int lean_lds_bytes = 10752;        // LDS per job of the lean walk kernel: 15 jobs per CU
+    int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: point walks skip the lean kernel (cross-check of it)
+    // queue of walk jobs the lean kernel leaves to the general one: a counter word, then the job indices
+    int* d_queue = nullptr;
+    size_t queue_jobs = 0;
     // growable device staging buffers used by the host-table entry points
     void* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -31,6 +36,10 @@ struct slam_level_dev {
     int w, h;
     long long pitch, frame_stride;
     float sub;
+    // derived on the host when the pyramid is created
+    float inv_sub;       // 1 / sub
+    float rad;           // Feature::track's search radius at this level (feature.cpp:134,136), before the level-0 stride factor
+    int pow2;            // sub is a power of two: x / sub == x * inv_sub exactly
 };
 
 struct slam_pyr_dev {
@@ -69,6 +78,9 @@ struct slam_pyr {
 
 int slam_set_error(slam_ctx* ctx, int code, const char* fmt, ...);
 int slam_stage_reserve(slam_ctx* ctx, int slot, size_t bytes);
+int slam_queue_reserve(slam_ctx* ctx, int njobs);
+int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
+                      size_t blob_bytes, slam_track_result* d_out, int* queue);
 
 #define SLAM_HIP_CHECK(ctx, call)                                                              \
     do {                                                                                       \
