@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../.."
 CS=slam_amd/csrc
 LIB=slam_amd/lib
-POINTS="2:2 2:50 2:51 2:52 2:53 2:54 2:55 1:2 0:2 0:50 0:51 0:52 0:53 0:54 0:55 -1:30"
+POINTS=${EXIT_SWEEP_POINTS:-"2:2 2:50 2:51 2:52 2:53 2:54 2:55 1:2 0:2 0:50 0:51 0:52 0:53 0:54 0:55 -1:30"}
 if [ "$1" = build ]; then
   mkdir -p $LIB/diag
   n=0
@@ -29,6 +29,10 @@ else
     lvl=${p%%:*}; id=${p##*:}
     SLAM_HIP_LIB=$PWD/$LIB/diag/libslam_hip_exit_${lvl}_$id.so timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES \
       -d $OUT/p_${lvl}_$id -o p -- python3 $PWD/profiles/tools/walk_probe.py 128 2 > $OUT/p_${lvl}_$id.log 2>&1
+    if [ -n "$EXIT_SWEEP_LDS" ]; then
+      SLAM_HIP_LIB=$PWD/$LIB/diag/libslam_hip_exit_${lvl}_$id.so timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU \
+        -d $OUT/p_${lvl}_$id/lds -o q -- python3 $PWD/profiles/tools/walk_probe.py 128 2 > $OUT/q_${lvl}_$id.log 2>&1
+    fi
     echo "level $lvl stamp $id"
     python3 profiles/tools/summarise_counters.py $OUT/p_${lvl}_$id track_lean | grep -v "^kernel" || true
   done

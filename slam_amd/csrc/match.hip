@@ -406,21 +406,37 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
     float response = 0.f, sdx = 0.f, sdy = 0.f;
     int levels_run = 0;
     const int nlev = pyr.nlev;
+    // Template size and cv::resize scale of every level do not depend on the walk's results: lane l computes the
+    // width and x scale of level l, lane 8 + l its height and y scale (feature.cpp:126-131); the level loop reads them
+    // back with readlane.
+    int lvl_t; double lvl_sc;
+    {
+        const int lane = lane_here();
+        const int q = min(lane & 7, nlev - 1);
+        const slam_level_dev& lq = pyr.lev[q];
+        const float sub = lq.sub;
+        const int src = (lane & 8) ? job.projh : job.projw;
+        lvl_t = src; lvl_sc = 1.0;
+        if (sub != 1.f) {                       // Size(projw/sub, projh/sub) truncates
+            lvl_t = (int)(lq.pow2 ? __fmul_rn((float)src, lq.inv_sub) : __fdiv_rn((float)src, sub));
+            if (lvl_t > 0) lvl_sc = resize_scale(src, lvl_t);
+        }
+    }
     for (int i = nlev - 1; i >= 0; --i) {
         STAMP_LEVEL(i);
         STAMP(2);
         const slam_level_dev& lv = pyr.lev[i];
         const float sub = lv.sub;
         const bool p2 = lv.pow2 != 0;           // dividing by a power of two and multiplying by its inverse are both exact
-        L.tw = job.projw; L.th = job.projh;     // feature.cpp:126-128
+        L.tw = __builtin_amdgcn_readlane(lvl_t, i); L.th = __builtin_amdgcn_readlane(lvl_t, 8 + i);
         L.resized = sub != 1.f;
-        L.scx = 1.0; L.scy = 1.0;
-        if (L.resized) {                        // feature.cpp:130-131, Size(projw/sub, projh/sub) truncates
-            L.tw = uni_i32((int)(p2 ? __fmul_rn((float)job.projw, lv.inv_sub) : __fdiv_rn((float)job.projw, sub)));
-            L.th = uni_i32((int)(p2 ? __fmul_rn((float)job.projh, lv.inv_sub) : __fdiv_rn((float)job.projh, sub)));
-            if (L.tw <= 0 || L.th <= 0) { LEAN_REJECT(11); return false; }
-            L.scx = resize_scale(job.projw, L.tw);
-            L.scy = resize_scale(job.projh, L.th);
+        if (L.tw <= 0 || L.th <= 0) { LEAN_REJECT(11); return false; }
+        {
+            const long long bx = __double_as_longlong(lvl_sc);
+            const unsigned xl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bx, i), xh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bx >> 32), i);
+            const unsigned yl = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bx, 8 + i), yh = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bx >> 32), 8 + i);
+            L.scx = __longlong_as_double((long long)(((unsigned long long)xh << 32) | xl));
+            L.scy = __longlong_as_double((long long)(((unsigned long long)yh << 32) | yl));
         }
         float rad = lv.rad;                     // feature.cpp:134 (coarsest) or :136 (finer)
         if (i == 0 && nlev > 1) rad = __fmul_rn(rad, (float)job.stride);        // feature.cpp:137-138

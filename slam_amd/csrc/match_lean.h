@@ -39,6 +39,26 @@ __device__ __forceinline__ bool span_ok(long long off, long long len, unsigned l
 __device__ __forceinline__ int uni_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float uni_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
+// Maximum / minimum over the wavefront with DPP moves (see wave_sum_u32); the result is wave-uniform.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(8), 0xf, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_BCAST15, 0xa, 0xf, false));
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_BCAST31, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, SLAM_DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, SLAM_DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, SLAM_DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, SLAM_DPP_ROW_SHR(8), 0xf, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, SLAM_DPP_BCAST15, 0xa, 0xf, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, SLAM_DPP_BCAST31, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 struct LeanLevel {           // wave-uniform description of one level's search
     const uint8_t* im;       // level image of the job's frame (4-byte aligned, pitch a multiple of 4)
     unsigned ipitch;
@@ -84,32 +104,43 @@ __device__ __forceinline__ int lean_pick_slices(int nunits, int nA, int nB, bool
     return best_s;
 }
 
+// accumulator index of the cell in tile column c (= o + x), row y, of a stride-1 search: strips of 4 columns run down
+// the rows (unit = strip * ah + row)
+__device__ __forceinline__ int lean_strip_cell(int c, int y, int ah) { return ((c >> 2) * ah + y) * 4 + (c & 3); }
+
 // the F32 score (matching.cpp:70-72) of a cell from its sums; the caller has checked that the cell is visited
 __device__ __forceinline__ float lean_score(const lds_u32* acc, int ai, float p2f) {
     return score_f32_n(acc[2 * ai], acc[2 * ai + 1], p2f);
 }
 
-// One entry of the lists for the NC cells of a unit: cc += <window, P0>, si += <window & M, window & M>.
+// One entry of the lists for the NC cells of a unit: cc += <window, P0>, si += <window & M, window & M>.  A tile entry
+// holds the byte windows W0 (bytes 0..3 from its position) and W3 (bytes 3..6); W1 and W2 are picked out of the two.
 template <int NC, bool MASKED>
 __device__ __forceinline__ void lean_step(const lds_u8* wp, unsigned P0, unsigned M, unsigned (&cc)[NC], unsigned (&si)[NC]) {
     if (NC == 4) {
-        const v4u32 w = *reinterpret_cast<const lds_v4u32*>(wp);
-        const unsigned w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
+        const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
+        const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
+        const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
         const unsigned m0 = MASKED ? (w0 & M) : w0, m1 = MASKED ? (w1 & M) : w1, m2 = MASKED ? (w2 & M) : w2, m3 = MASKED ? (w3 & M) : w3;
         cc[0] = __builtin_amdgcn_udot4(w0, P0, cc[0], false); si[0] = __builtin_amdgcn_udot4(m0, m0, si[0], false);
         cc[1 % NC] = __builtin_amdgcn_udot4(w1, P0, cc[1 % NC], false); si[1 % NC] = __builtin_amdgcn_udot4(m1, m1, si[1 % NC], false);
         cc[2 % NC] = __builtin_amdgcn_udot4(w2, P0, cc[2 % NC], false); si[2 % NC] = __builtin_amdgcn_udot4(m2, m2, si[2 % NC], false);
         cc[3 % NC] = __builtin_amdgcn_udot4(w3, P0, cc[3 % NC], false); si[3 % NC] = __builtin_amdgcn_udot4(m3, m3, si[3 % NC], false);
     } else {
-        const unsigned w = *reinterpret_cast<const lds_u32*>(wp);
+        // the cell's window starts k = 0..3 bytes into the entry: k = 0 and 3 are stored, 1 and 2 picked
+        const unsigned k = (unsigned)(reinterpret_cast<unsigned long long>(wp)) & 7u;     // entries are 8-byte aligned; k rides in the low bits
+        const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp - k);
+        const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
+        const unsigned sel = k == 0 ? 0x03020100u : k == 1 ? 0x05030201u : k == 2 ? 0x06050302u : 0x07060504u;
+        const unsigned w = __builtin_amdgcn_perm(w3, w0, sel);
         const unsigned m0 = MASKED ? (w & M) : w;
         cc[0] = __builtin_amdgcn_udot4(w, P0, cc[0], false); si[0] = __builtin_amdgcn_udot4(m0, m0, si[0], false);
     }
 }
 
 // Tasks are dealt slice-major (task = slice * nunits + unit): neighbouring lanes then hold neighbouring units of one
-// slice, so an entry read is one broadcast address and the window reads of a lane group fall on consecutive 16-byte
-// tile entries (distinct banks).  Entries are fetched four ahead of their use; the lists are padded so that reading
+// slice, so an entry read is one broadcast address and the window reads of a lane group fall on 16-byte tile entries an
+// odd number of entries apart (distinct banks).  Entries are fetched four ahead of their use; the lists are padded so that reading
 // up to four entries past a slice stays inside them.
 template <int NC>
 __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u64* list, const lds_u32* marr, lds_u32* acc,
@@ -120,10 +151,11 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
     for (int t0 = 0; t0 < ntask; t0 += SLAM_WG) {
         const int task = min(t0 + lane, ntask - 1);        // surplus lanes repeat the last task and do not flush
         const int slice = (int)(((float)task + 0.5f) * rnu), unit = task - slice * nunits;
-        const int uy = (int)(((float)unit + 0.5f) * rdu), ux = unit - uy * div_units;
+        // strips run down the columns (unit = strip * rows + row): neighbouring lanes are tp entries apart, and tp is odd
+        const int uq = (int)(((float)unit + 0.5f) * rdu), um = unit - uq * div_units;
         unsigned tb;                                       // byte offset of the unit's first window in the tile
-        if (NC == 4) tb = (unsigned)(uy * tp + ux) * 16u;
-        else { const int bx = o + ux * step; tb = (unsigned)((uy * step) * tp + (bx >> 2)) * 16u + (unsigned)(bx & 3) * 4u; }
+        if (NC == 4) tb = (unsigned)(um * tp + uq) * 8u;
+        else { const int bx = o + um * step; tb = (unsigned)((uq * step) * tp + (bx >> 2)) * 8u + (unsigned)(bx & 3); }
         const lds_u8* tl = tile + tb;
         unsigned cc[NC], si[NC];
 #pragma unroll
@@ -180,12 +212,12 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const bool strips = L.step == 1;
     const int nx = strips ? L.aw : (L.aw + L.step - 1) / L.step, ny = strips ? L.ah : (L.ah + L.step - 1) / L.step;
     const int cols = (o + L.aw + 3) >> 2;                  // dword columns that hold a cell's first pixel
-    const int tp = cols + G - 1;                           // window positions per tile row
+    const int tp = (cols + G - 1) | 1;                     // window positions per tile row, odd: see lean_accumulate
     const int trows = L.ah + L.th - 1;
     const int nunits = strips ? cols * L.ah : nx * ny;
     const int nacc = strips ? nunits * 4 : nunits;
     const int cap = NG + LEAN_MAX_S + 8;                   // room for the padding entries and for reads a few entries ahead
-    const int tile_bytes = trows * tp * 16;
+    const int tile_bytes = (trows * tp * 8 + 15) & ~15;
     const int raw_bytes = NG * 8 + (L.resized ? (G * 4 + L.th) * 8 : 0);
     const int acc_bytes = (nacc * 8 + 15) & ~15;
     const int list_bytes = cap * 8, marr_bytes = (cap * 4 + 15) & ~15;
@@ -243,7 +275,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         lds_u8* rb = reinterpret_cast<lds_u8*>(raw);
         const float rw = __builtin_amdgcn_rcpf((float)wpx);
         const int n = L.th * wpx;
-        constexpr int NB = 2;
+        constexpr int NB = 1;
         for (int i0 = 0; i0 < n; i0 += NB * SLAM_WG) {
             ResizeSrc spx[NB], smx[NB];
             unsigned long long txq[NB], tyq[NB];
@@ -299,7 +331,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             const bool isA = M == 0xFFFFFFFFu, isB = M != 0u && !isA;
             const unsigned long long ba = __ballot(isA), bb = __ballot(isB);
             const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G;
-            const unsigned long long en = ((unsigned long long)((unsigned)(u * tp + gq) * 16u) << 32) | P0;
+            const unsigned long long en = ((unsigned long long)((unsigned)(u * tp + gq) * 8u) << 32) | P0;
             const unsigned long long below = (1ull << lane) - 1ull;
             // the raw region is read above and the lists written below live in different LDS ranges
             if (isA) { const int p = baseA + __builtin_popcountll(ba & below); list[p] = en; marr[p] = M; }
@@ -311,32 +343,40 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     __syncthreads();                                        // raw and taps are dead: the tile goes over them
     STAMP(52);
 
-    // ---- image tile: four byte windows per dword position ---------------------------------------------------------
+    // ---- image tile: byte windows W0 and W3 of every dword position ----------------------------------------------------
     {
-        const int lg = 32 - __builtin_clz((unsigned)tp);   // tp + 1 <= 2^lg lanes per row: the last one only feeds its dword
+        const int lg = 32 - __builtin_clz((unsigned)tp);   // 2^lg > tp lanes per tile row
         const int c = lane & ((1 << lg) - 1), lr = lane >> lg, rpp = SLAM_WG >> lg;
-        const unsigned dcol = (unsigned)((L.x0 - o) >> 2) + (unsigned)c;
-        const bool ok0 = c < tp && (int)(dcol * 4 + 4) <= L.w, ok1 = c < tp && (int)(dcol * 4 + 8) <= L.w;
-        const uint8_t* src = L.im + (unsigned long long)L.y0 * L.ipitch;
-        unsigned go = (unsigned)lr * L.ipitch + dcol * 4u;
-        unsigned to = (unsigned)(lr * tp + c) * 16u;
-        for (int r = lr; r < trows; r += rpp) {
-            unsigned d0 = 0, d1 = 0;
-            if (ok0) d0 = *reinterpret_cast<const unsigned*>(src + go);
-            if (ok1) d1 = *reinterpret_cast<const unsigned*>(src + go + 4);
-            if (c < tp) {
-                v4u32 wv;
-                wv.x = d0; wv.y = __builtin_amdgcn_alignbyte(d1, d0, 1); wv.z = __builtin_amdgcn_alignbyte(d1, d0, 2); wv.w = __builtin_amdgcn_alignbyte(d1, d0, 3);
-                *reinterpret_cast<lds_v4u32*>(tile + to) = wv;
+        if (c < tp) {
+            // Bytes past the image row's last whole dword are only ever read for padding cells and padding template
+            // columns (whose sums are dropped or masked to zero), and rows past the tile by nobody: such loads are
+            // clamped onto valid dwords instead of being predicated.
+            const unsigned lastd = (unsigned)(L.w >> 2) - 1u;
+            const unsigned dcol = (unsigned)((L.x0 - o) >> 2) + (unsigned)c;
+            const unsigned g0 = min(dcol, lastd) * 4u, g1 = min(dcol + 1u, lastd) * 4u;
+            const uint8_t* src = L.im + (unsigned long long)L.y0 * L.ipitch;
+            const int nit = (trows + rpp - 1) / rpp;       // wave-uniform
+            for (int it = 0; it < nit; it += 4) {
+                unsigned d0[4], d1[4], ro[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    ro[q] = (unsigned)min(lr + (it + q) * rpp, trows - 1);
+                    d0[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g0);
+                    d1[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g1);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned w3 = __builtin_amdgcn_alignbyte(d1[q], d0[q], 3);
+                    *reinterpret_cast<lds_u64*>(tile + (ro[q] * (unsigned)tp + (unsigned)c) * 8u) = ((unsigned long long)w3 << 32) | d0[q];
+                }
             }
-            go += (unsigned)rpp * L.ipitch; to += (unsigned)(rpp * tp) * 16u;
         }
     }
     __syncthreads();
     STAMP(53);
 
     // ---- sums -------------------------------------------------------------------------------------------------------
-    if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, cols, tp, o, 1);
+    if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, L.ah, tp, o, 1);
     else lean_accumulate<1>(tile, list, marr, acc, nunits, S, na, nb, nA1, nx, tp, o, L.step);
     __syncthreads();
     STAMP(54);
@@ -344,45 +384,61 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     // ---- scores and argmax (cv::minMaxLoc: first maximum in row-major order, NaN never wins) ---------------------------
     const int ncell = nx * ny;
     const float rnx = __builtin_amdgcn_rcpf((float)nx);
-    const int arow = strips ? cols * 4 : nx;               // accumulator pitch in cells
-    const bool prune = ncell > SLAM_WG && nm.tn > 0.0;
-    const float rn = __builtin_amdgcn_rcpf(nm.p2f);
-    float keep_from = -FLT_MAX;
-    if (prune) {
-        // single-precision estimates (relative error below 1e-6); only cells within 1e-5 of the largest can hold the
-        // maximum or tie with it, and only those are scored with the exact formula
-        float m = -FLT_MAX;
+    Best b = {-FLT_MAX, INT_MAX};
+    constexpr int NQ = 8;
+    if (ncell <= SLAM_WG) {                                // one cell per lane
+        if (lane < ncell) {
+            const int cy = (int)(((float)lane + 0.5f) * rnx), cx = lane - cy * nx;
+            const int x = cx * L.step, y = cy * L.step;
+            if (!(L.amask && L.amask[y * L.aw + x] == 0))
+                best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, y, L.ah) : lane, nm.p2f), (y << 16) | x);
+        }
+    } else if (ncell <= NQ * SLAM_WG && nm.tn > 0.0) {
+        // Single-precision estimates first (relative error below 1e-6): only cells within 1e-5 of the largest estimate
+        // can hold the maximum or tie with it, and only those are scored with the exact formula.  -FLT_MAX marks cells
+        // that are not visited or whose exact score is NaN (an all-zero window).
+        const float rn = __builtin_amdgcn_rcpf(nm.p2f);
+        float est[NQ], m = -FLT_MAX;
+        int ai[NQ], key[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            est[q] = -FLT_MAX; ai[q] = 0; key[q] = 0;
+            if (q * SLAM_WG < ncell) {
+                const int i = q * SLAM_WG + lane;
+                const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+                const int x = cx * L.step, y = cy * L.step;
+                if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0)) {
+                    ai[q] = strips ? lean_strip_cell(o + x, y, L.ah) : i;
+                    key[q] = (y << 16) | x;
+                    const unsigned CC = acc[2 * ai[q]], SI = acc[2 * ai[q] + 1];
+                    if (SI != 0u) est[q] = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+                }
+                m = fmaxf(m, est[q]);
+            }
+        }
+        // estimates are >= 0 or the marker, so their bit patterns order like the values once the marker is mapped to 0
+        m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
+        const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            if (q * SLAM_WG < ncell && est[q] != -FLT_MAX && est[q] >= keep_from) best_update(b, lean_score(acc, ai[q], nm.p2f), key[q]);
+    } else {
         for (int i = lane; i < ncell; i += SLAM_WG) {
             const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
             const int x = cx * L.step, y = cy * L.step;
             if (L.amask && L.amask[y * L.aw + x] == 0) continue;
-            const int ai = strips ? (y * arow + o + x) : i;
-            const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
-            if (SI != 0u) m = fmaxf(m, (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn);
+            best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, y, L.ah) : i, nm.p2f), (y << 16) | x);
         }
-#pragma unroll
-        for (int d = 1; d < SLAM_WG; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
-        keep_from = m - 1e-5f * fmaxf(m, 1.f);
     }
-    Best b = {-FLT_MAX, INT_MAX};
-    for (int i = lane; i < ncell; i += SLAM_WG) {
-        const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
-        const int x = cx * L.step, y = cy * L.step;
-        if (L.amask && L.amask[y * L.aw + x] == 0) continue;
-        const int ai = strips ? (y * arow + o + x) : i;
-        if (prune) {
-            const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
-            if (SI == 0u || !((float)CC * __builtin_amdgcn_rsqf((float)SI) * rn >= keep_from)) continue;
-        }
-        best_update(b, lean_score(acc, ai, nm.p2f), (y << 16) | x);
-    }
-    b = best_wave(b);
-    const int bidx = uni_i32(b.idx);
-    const float bv = uni_f32(b.v);
+    // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The wave's
+    // maximum first, then the smallest cell index among the lanes that hold it.
+    const unsigned bkey = wave_max_u32(b.idx != INT_MAX ? __float_as_uint(b.v) + 1u : 0u);
+    const int bidx = (int)wave_min_u32((b.idx != INT_MAX && __float_as_uint(b.v) + 1u == bkey) ? (unsigned)b.idx : 0xFFFFFFFFu);
+    const float bv = __uint_as_float(bkey - 1u);
     STAMP(55);
     // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is a
     // -1 of the untouched score map or there is none at all: the general kernel knows those cases.
-    if (!(bv >= 0.f) || bidx == INT_MAX) { LEAN_REJECT(3); return out; }
+    if (bkey == 0u) { LEAN_REJECT(3); return out; }
     const int lx = bidx & 0xffff, ly = bidx >> 16;
     out.ok = true;
     out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
@@ -394,7 +450,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int qx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0), qy = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
     const bool in = qx >= 0 && qy >= 0 && qx < L.aw && qy < L.ah;
     float v = -1.f;
-    if (in && !(L.amask && L.amask[qy * L.aw + qx] == 0)) v = lean_score(acc, qy * arow + o + qx, nm.p2f);
+    if (in && !(L.amask && L.amask[qy * L.aw + qx] == 0)) v = lean_score(acc, lean_strip_cell(o + qx, qy, L.ah), nm.p2f);
     const float sl = __shfl(v, 0, 64), sr = __shfl(v, 1, 64), su = __shfl(v, 2, 64), sd = __shfl(v, 3, 64);
     const bool okl = __shfl((int)in, 0, 64) != 0, okr = __shfl((int)in, 1, 64) != 0;
     const bool oku = __shfl((int)in, 2, 64) != 0, okd = __shfl((int)in, 3, 64) != 0;

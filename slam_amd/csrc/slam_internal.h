@@ -20,7 +20,7 @@ struct slam_ctx {
     int line_lds_bytes = 12 * 1024;    // the same for line walks: 12 jobs per CU (3 per SIMD), large descriptors
     int match_lds_bytes = 9 * 1024;    // LDS per search job: 16 jobs share a CU's 160 KB, as many as its registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
     int force_direct = 0;   // SLAM_HIP_FORCE_DIRECT=1: search by direct evaluation (cross-check of the tiled core)
-    int lean_lds_bytes = 10752;        // LDS per job of the lean walk kernel: 15 jobs per CU
+    int lean_lds_bytes = 8192;         // LDS per job of the lean walk kernel: 20 jobs per CU
     int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: point walks skip the lean kernel (cross-check of it)
     // queue of walk jobs the lean kernel leaves to the general one: a counter word, then the job indices
     int* d_queue = nullptr;
