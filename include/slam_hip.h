@@ -183,6 +183,17 @@ int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_
                            int njobs, const uint8_t* d_blob, size_t blob_bytes,
                            slam_track_result* d_out);
 
+/* slam_hip_track_batch_d for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same results;
+ * the queue of jobs the lean walk kernel hands to the general one lives in a fixed array inside the library's code
+ * object (one copy per GPU, about 4 MB, held until the process ends) instead of a buffer the context grows on demand,
+ * and the call makes no hipMalloc / hipFree or any other allocating call.  At most 1 048 576 jobs per call
+ * (SLAM_HIP_ECAP beyond that).  All calls on one GPU share that array: calls that overlap on one GPU (different
+ * streams or contexts) race; calls on one stream are ordered and each clears what it needs first. */
+int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs,
+                                   int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                                   slam_track_result* d_out);
+
 /* ---------------------------------------------------------------------------------------------
  * Corner detection — replaces cv::FAST(im, keypoints, threshold, nonmaxSuppression) as called by
  * SLAM::getSortedKeyPoints (new_point.cpp:120) and that function itself (SLAM.hpp:118-119,

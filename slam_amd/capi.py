@@ -116,6 +116,7 @@ SIGNATURES = {
                                                  C.c_int, C.c_int, _P, C.POINTER(MatchResult)]),
     "slam_hip_track_batch": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "slam_hip_track_batch_d": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "slam_hip_track_batch_noalloc_d": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "slam_hip_fast_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "slam_hip_fast_detect_d": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int,
                                          C.c_int, _P, C.c_int, _P, _P, C.c_size_t]),

@@ -49,6 +49,13 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     c->no_lean = (nl && nl[0] == '1') ? 1 : 0;
     const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");
     if (lk && atoi(lk) >= 4 && atoi(lk) <= 63) c->match_lds_bytes = c->line_lds_bytes = atoi(lk) * 1024;
+    const int rc = slam_track_scratch_init(c);             // this device's copy of the no-alloc walk queue
+    if (rc != SLAM_HIP_OK) {
+        strncpy(g_create_err, c->err, sizeof(g_create_err) - 1);
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return rc;
+    }
     *out = c;
     return SLAM_HIP_OK;
 }

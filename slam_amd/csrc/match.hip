@@ -606,6 +606,29 @@ int check_pyr(slam_ctx* ctx, const slam_pyr* pyr, const char* who) {
 
 }  // namespace
 
+// Queue storage of slam_hip_track_batch_noalloc_d: device memory that exists as long as the code object is loaded, one
+// copy per GPU.  Host code never uses this name as an address; it asks the runtime for the device address once per
+// device (slam_track_scratch_init) and passes that pointer to the kernels like any other queue.
+#define SLAM_NOALLOC_MAX_JOBS (1 << 20)
+static __device__ __align__(256) int g_walk_scratch[SLAM_DEFER_LIST + SLAM_NOALLOC_MAX_JOBS];
+
+#define SLAM_MAX_DEVICES 64
+static int* g_walk_scratch_ptr[SLAM_MAX_DEVICES] = {nullptr};
+
+// Called by slam_hip_create with the context's device current.
+int slam_track_scratch_init(slam_ctx* ctx) {
+    if (ctx->device < 0 || ctx->device >= SLAM_MAX_DEVICES) return SLAM_HIP_OK;      // such a device simply has no no-alloc entry point
+    if (g_walk_scratch_ptr[ctx->device]) return SLAM_HIP_OK;
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_walk_scratch));
+    if (e != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return slam_set_error(ctx, SLAM_HIP_EHIP, "hipGetSymbolAddress(walk scratch) on device %d: %s", ctx->device, hipGetErrorString(e));
+    }
+    g_walk_scratch_ptr[ctx->device] = (int*)p;
+    return SLAM_HIP_OK;
+}
+
 #ifdef SLAM_STAMPS
 extern "C" int slam_hip_debug_set_stamps(void* d_ptr) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_slam_stamps), &d_ptr, sizeof(void*)) == hipSuccess ? 0 : -2;
@@ -749,6 +772,30 @@ int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* 
                        0, ctx->match_lds_bytes, (const int*)queue);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs,
+                                              int njobs, const uint8_t* d_blob, size_t blob_bytes,
+                                              slam_track_result* d_out) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (njobs < 0 || (njobs > 0 && (!d_jobs || !d_blob || !d_out)))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch_noalloc: null table or negative count");
+    if (njobs > SLAM_NOALLOC_MAX_JOBS)
+        return slam_set_error(ctx, SLAM_HIP_ECAP, "track_batch_noalloc: %d jobs, at most %d per call", njobs, SLAM_NOALLOC_MAX_JOBS);
+    int rc = check_pyr(ctx, pyr, "track_batch_noalloc");
+    if (rc != SLAM_HIP_OK) return rc;
+    if (njobs == 0) return SLAM_HIP_OK;
+    int* q = (ctx->device >= 0 && ctx->device < SLAM_MAX_DEVICES) ? g_walk_scratch_ptr[ctx->device] : nullptr;
+    if (!q) return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch_noalloc: no scratch on device %d", ctx->device);
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->force_direct || ctx->no_lean) {               // diagnostic settings: every job through the general kernel, no queue
+        hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
+                           ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
+                           ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
+        SLAM_HIP_CHECK(ctx, hipGetLastError());
+        return SLAM_HIP_OK;
+    }
+    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, q);
 }
 
 extern "C" int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs,

@@ -79,6 +79,7 @@ struct slam_pyr {
 int slam_set_error(slam_ctx* ctx, int code, const char* fmt, ...);
 int slam_stage_reserve(slam_ctx* ctx, int slot, size_t bytes);
 int slam_queue_reserve(slam_ctx* ctx, int njobs);
+int slam_track_scratch_init(slam_ctx* ctx);
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
                       size_t blob_bytes, slam_track_result* d_out, int* queue);
 
