@@ -444,9 +444,13 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
 
     def go():
         capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), len(jobs), P(d_blob), blob.size, P(d_res)))
+    # 31x31 templates: the lean walk kernel needs 11 KB of LDS per walk for the full-resolution level (include/slam_hip.h)
+    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 11264))
     go()
     torch.cuda.synchronize()
     res = d_res.cpu().numpy().view(TRACK_RES_DT)
+    deferred = C.c_int32(0)
+    capi.check(ctx.handle, L.slam_hip_debug_walk_deferred(ctx.handle, C.byref(deferred)))
     assert (res["status"] == 0).all()
     parity = None
     if not args.no_cpu:
@@ -475,11 +479,13 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
     macs = float((ran * c3 * 2 * tw3 * tw3 + cum_m[np.maximum(lr - 1, 0)]).sum())
     ms = timed(stream, go, max(5, args.steps))
     ms_p = timed(stream, lambda: pyr.rebuild_d(d_fr.data_ptr(), w, w * h), max(5, args.steps))
-    out = search_report("c3_track_kernel", "track_kernel", ms, positions, alg, macs, traffic,
+    out = search_report("c3_track_kernel", "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
                         {"workload": "C3: %dx%d, %d features/frame, %dx%d masked templates, pyramid {1,2,4,8}, ellipse windows "
                                      "(area masks) on the coarsest level, stride 3; %d frames" % (w, h, nfeat, ts, ts, nfr),
                          "jobs": len(jobs), "pyramid_ms": ms_p, "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
-                         "walked_all_levels": float((lr == 4).mean()), "parity": parity})
+                         "walked_all_levels": float((lr == 4).mean()), "jobs_left_to_general_kernel": deferred.value,
+                         "walk_lds_bytes": 11264, "parity": parity})
+    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 8192))
     pyr.close()
     return out
 

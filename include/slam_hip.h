@@ -56,6 +56,12 @@ int slam_hip_synchronize(slam_ctx* ctx);
  * adds jobs per CU; more LDS cuts large templates into fewer chunks at the price of fewer jobs per CU.
  * Results do not depend on it. */
 int slam_hip_set_match_lds(slam_ctx* ctx, int bytes);
+/* LDS bytes per job of the lean point-walk kernel (the first of the two kernels behind slam_hip_track_batch[_d]): a
+ * multiple of 1024 in [4096, 65536], default 8192 (20 walks share a CU).  A walk any of whose levels needs more - the
+ * image tile under the window, the template's entry list and the score cells together - is left to the general
+ * kernel, so raise it for templates beyond about 24x24 at full resolution (31x31 templates in 17x17 windows need
+ * 12288).  Results do not depend on it. */
+int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes);
 /* Text of the last error on ctx (or of the last failed slam_hip_create when ctx is NULL). */
 const char* slam_hip_last_error_string(const slam_ctx* ctx);
 

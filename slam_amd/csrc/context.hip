@@ -47,6 +47,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     c->force_direct = (fd && fd[0] == '1') ? 1 : 0;
     const char* nl = getenv("SLAM_HIP_NO_LEAN");
     c->no_lean = (nl && nl[0] == '1') ? 1 : 0;
+    const char* wk = getenv("SLAM_HIP_WALK_LDS_KB");
+    if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) c->lean_lds_bytes = atoi(wk) * 1024;
     const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");
     if (lk && atoi(lk) >= 4 && atoi(lk) <= 63) c->match_lds_bytes = c->line_lds_bytes = atoi(lk) * 1024;
     const int rc = slam_track_scratch_init(c);             // this device's copy of the no-alloc walk queue
@@ -66,7 +68,9 @@ extern "C" int slam_hip_destroy(slam_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 4; i++)
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+    if (ctx->mfa_pyr) { slam_hip_pyramid_destroy(ctx, ctx->mfa_pyr); ctx->mfa_pyr = nullptr; }
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SLAM_HIP_OK;
@@ -84,6 +88,14 @@ extern "C" int slam_hip_set_match_lds(slam_ctx* ctx, int bytes) {
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_match_lds: %d not a multiple of 1024 in [4096, 64512]", bytes);
     ctx->match_lds_bytes = bytes;
     ctx->line_lds_bytes = bytes;
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (bytes < 4096 || bytes > 65536 || (bytes & 1023))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_walk_lds: %d not a multiple of 1024 in [4096, 65536]", bytes);
+    ctx->lean_lds_bytes = bytes;
     return SLAM_HIP_OK;
 }
 
@@ -146,6 +158,40 @@ int slam_stage_reserve(slam_ctx* ctx, int slot, size_t bytes) {
         return slam_set_error(ctx, SLAM_HIP_ENOMEM, "staging hipMalloc(%zu): %s", want, hipGetErrorString(e));
     }
     ctx->stage_bytes[slot] = want;
+    return SLAM_HIP_OK;
+}
+
+#define SLAM_PIN_MAX (64u << 20)      // larger batches fall back to the runtime's 2-D copy
+
+int slam_upload_image(slam_ctx* ctx, uint8_t* d_dst, size_t dpitch, const uint8_t* h_src, size_t spitch, size_t width, size_t rows,
+                      size_t slot_off) {
+    const size_t bytes = dpitch * rows;
+    if (rows == 0 || width == 0) return SLAM_HIP_OK;
+    if (slot_off + bytes > SLAM_PIN_MAX) {
+        SLAM_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, dpitch, h_src, spitch, width, rows, hipMemcpyHostToDevice, ctx->stream));
+        return SLAM_HIP_OK;
+    }
+    if (slot_off + bytes > ctx->pin_bytes) {
+        if (slot_off != 0) {          // never move the buffer while earlier images of this call are still leaving it
+            SLAM_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, dpitch, h_src, spitch, width, rows, hipMemcpyHostToDevice, ctx->stream));
+            return SLAM_HIP_OK;
+        }
+        SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; ctx->pin_bytes = 0; }
+        size_t want = bytes * 4 < SLAM_PIN_MAX ? bytes * 4 : SLAM_PIN_MAX;
+        if (want < (1u << 20)) want = 1u << 20;
+        if (hipHostMalloc((void**)&ctx->h_pin, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->h_pin = nullptr;
+            SLAM_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, dpitch, h_src, spitch, width, rows, hipMemcpyHostToDevice, ctx->stream));
+            return SLAM_HIP_OK;
+        }
+        ctx->pin_bytes = want;
+    }
+    uint8_t* stage = ctx->h_pin + slot_off;
+    if (spitch == dpitch) memcpy(stage, h_src, spitch * (rows - 1) + width);
+    else for (size_t r = 0; r < rows; r++) memcpy(stage + r * dpitch, h_src + r * spitch, width);
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, stage, dpitch * (rows - 1) + width, hipMemcpyHostToDevice, ctx->stream));
     return SLAM_HIP_OK;
 }
 

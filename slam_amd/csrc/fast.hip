@@ -486,10 +486,11 @@ static int fast_upload(slam_ctx* ctx, const uint8_t* h_frames, int w, int h, siz
     dstride = dpitch * (size_t)h;
     int rc = slam_stage_reserve(ctx, 0, dstride * (size_t)nframes);
     if (rc != SLAM_HIP_OK) return rc;
-    for (int f = 0; f < nframes; f++)
-        SLAM_HIP_CHECK(ctx, hipMemcpy2DAsync((uint8_t*)ctx->d_stage[0] + (size_t)f * dstride, dpitch,
-                                             h_frames + (size_t)f * frame_stride, pitch, (size_t)w, (size_t)h,
-                                             hipMemcpyHostToDevice, ctx->stream));
+    for (int f = 0; f < nframes; f++) {
+        rc = slam_upload_image(ctx, (uint8_t*)ctx->d_stage[0] + (size_t)f * dstride, dpitch, h_frames + (size_t)f * frame_stride, pitch,
+                               (size_t)w, (size_t)h, (size_t)f * dstride);
+        if (rc != SLAM_HIP_OK) return rc;
+    }
     return SLAM_HIP_OK;
 }
 
@@ -501,6 +502,7 @@ extern "C" int slam_hip_fast_detect(slam_ctx* ctx, const uint8_t* h_frames, int 
         (nframes > 1 && frame_stride < pitch * (size_t)h))
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "fast_detect: bad arguments");
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     size_t dpitch, dstride;
     int rc = fast_upload(ctx, h_frames, w, h, pitch, frame_stride, nframes, dpitch, dstride);
     if (rc != SLAM_HIP_OK) return rc;
@@ -515,6 +517,7 @@ extern "C" int slam_hip_get_sorted_keypoints(slam_ctx* ctx, const uint8_t* im, i
     if (!im || !fast_threshold || !out || !n_out || w < 1 || h < 1 || cap < 1 || pitch < (size_t)w)
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "get_sorted_keypoints: bad arguments");
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     size_t dpitch, dstride;
     int rc = fast_upload(ctx, im, w, h, pitch, pitch * (size_t)h, 1, dpitch, dstride);
     if (rc != SLAM_HIP_OK) return rc;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
     if (j >= njobs) return;
     const slam_match_job job = jobs[j];
     bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.level >= 0 && job.level < pyr.nlev &&
-              job.pw >= 1 && job.ph >= 1 && job.pw <= 32767 && job.ph <= 32767 && job.stride >= 1 &&
+              job.pw >= 1 && job.ph >= 1 && job.pw <= 32767 && job.ph <= 32767 && job.stride >= 1 && job.stride <= (1 << 20) &&
               job.aw <= (1 << 20) && job.ah <= (1 << 20) &&
               job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28);
     const long long pbytes = (long long)job.pw * job.ph;
@@ -417,10 +417,25 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
         const float sub = lq.sub;
         const int src = (lane & 8) ? job.projh : job.projw;
         lvl_t = src; lvl_sc = 1.0;
+        int oth = (lane & 8) ? job.projw : job.projh;             // the level's other template side
         if (sub != 1.f) {                       // Size(projw/sub, projh/sub) truncates
             lvl_t = (int)(lq.pow2 ? __fmul_rn((float)src, lq.inv_sub) : __fdiv_rn((float)src, sub));
+            oth = (int)(lq.pow2 ? __fmul_rn((float)oth, lq.inv_sub) : __fdiv_rn((float)oth, sub));
             if (lvl_t > 0) lvl_sc = resize_scale(src, lvl_t);
         }
+        // Does every level fit this kernel's LDS?  Decided here from the sizes alone (lanes 0..nlev-1, one level each), so
+        // that a walk the general kernel must take is handed over before any of its levels has been searched.
+        bool fits = true;
+        if (lane < nlev && lvl_t > 0 && oth > 0) {
+            float rad = lq.rad;
+            if (q == 0 && nlev > 1) rad = __fmul_rn(rad, (float)job.stride);
+            int aw = round_f2i(__fadd_rn(__fmul_rn(2.f, rad), 1.f)), ah = aw;
+            if (coarse_area && q == nlev - 1) { aw = job.aw; ah = job.ah; }
+            const int step = q == 0 ? 1 : job.stride;
+            const int nx = step == 1 ? aw : small_div(aw + step - 1, step), ny = step == 1 ? ah : small_div(ah + step - 1, step);
+            fits = aw >= 1 && ah >= 1 && aw <= 255 && ah <= 255 && lean_need(lvl_t, oth, aw, ah, step, nx, ny, sub != 1.f) <= lds_total;
+        }
+        if (__ballot(!fits) != 0ull) { LEAN_REJECT(13); return false; }
     }
     for (int i = nlev - 1; i >= 0; --i) {
         STAMP_LEVEL(i);
@@ -673,6 +688,7 @@ static int match_batch_host(slam_ctx* ctx, const slam_pyr* pyr, const slam_match
             return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_batch: job %d: patch mask values must be 0 or 1", i);
     }
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t jb = sizeof(slam_match_job) * (size_t)njobs, rb = sizeof(slam_match_result) * (size_t)njobs;
     if ((rc = slam_stage_reserve(ctx, 0, jb)) || (rc = slam_stage_reserve(ctx, 1, blob_bytes + 16)) ||
         (rc = slam_stage_reserve(ctx, 2, rb)) || (h_scores && (rc = slam_stage_reserve(ctx, 3, scores_len * 4))))
@@ -709,30 +725,35 @@ extern "C" int slam_hip_match_feature_in_area(slam_ctx* ctx,
         im_pitch < (size_t)w || patch_pitch < (size_t)pw || (patch_mask && pmask_pitch < (size_t)pw) ||
         (area_mask && (area_w < 1 || area_h < 1 || amask_pitch < (size_t)area_w)))
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_feature_in_area: bad arguments");
-    const float one = 1.f;
-    slam_pyr* pyr = nullptr;
-    int rc = slam_hip_pyramid_create(ctx, w, h, 1, &one, 1, &pyr);
-    if (rc != SLAM_HIP_OK) return rc;
-    rc = slam_hip_pyramid_build(ctx, pyr, im, im_pitch, im_pitch * (size_t)h);
-    if (rc == SLAM_HIP_OK) {
-        const size_t pb = (size_t)pw * ph, ab = area_mask ? (size_t)area_w * area_h : 0;
-        std::vector<uint8_t> blob(pb * (patch_mask ? 2 : 1) + ab);
-        for (int r = 0; r < ph; r++) memcpy(&blob[(size_t)r * pw], patch + (size_t)r * patch_pitch, (size_t)pw);
-        if (patch_mask) for (int r = 0; r < ph; r++) memcpy(&blob[pb + (size_t)r * pw], patch_mask + (size_t)r * pmask_pitch, (size_t)pw);
-        const size_t aoff = pb * (patch_mask ? 2 : 1);
-        if (area_mask) for (int r = 0; r < area_h; r++) memcpy(&blob[aoff + (size_t)r * area_w], area_mask + (size_t)r * amask_pitch, (size_t)area_w);
-        slam_match_job job;
-        job.frame = 0; job.level = 0; job.pw = pw; job.ph = ph;
-        job.patch_off = 0; job.pmask_off = patch_mask ? (int64_t)pb : -1;
-        job.ax = area_x; job.ay = area_y; job.aw = area_w; job.ah = area_h;
-        job.amask_off = area_mask ? (int64_t)aoff : -1;
-        job.stride = stride; job.use_exact_area_mask = use_exact_area_mask;
-        job.score_off = h_scores ? 0 : -1;
-        const size_t slen = h_scores ? (size_t)(area_w > 0 ? area_w : 0) * (size_t)(area_h > 0 ? area_h : 0) : 0;
-        rc = match_batch_host(ctx, pyr, &job, 1, blob.data(), blob.size(), slen ? h_scores : nullptr, slen, out);
+    // One-level pyramid kept in the context and reused while the image size stays the same: a call costs the upload of
+    // the image and of the job, no device allocation.
+    int rc = SLAM_HIP_OK;
+    if (!ctx->mfa_pyr || ctx->mfa_w != w || ctx->mfa_h != h) {
+        if (ctx->mfa_pyr) { slam_hip_pyramid_destroy(ctx, ctx->mfa_pyr); ctx->mfa_pyr = nullptr; }
+        const float one = 1.f;
+        rc = slam_hip_pyramid_create(ctx, w, h, 1, &one, 1, &ctx->mfa_pyr);
+        if (rc != SLAM_HIP_OK) { ctx->mfa_pyr = nullptr; return rc; }
+        ctx->mfa_w = w; ctx->mfa_h = h;
     }
-    slam_hip_pyramid_destroy(ctx, pyr);
-    return rc;
+    slam_pyr* pyr = ctx->mfa_pyr;
+    rc = slam_hip_pyramid_build(ctx, pyr, im, im_pitch, im_pitch * (size_t)h);
+    if (rc != SLAM_HIP_OK) return rc;
+    const size_t pb = (size_t)pw * ph, ab = area_mask ? (size_t)area_w * area_h : 0;
+    std::vector<uint8_t> blob(pb * (patch_mask ? 2 : 1) + ab);
+    for (int r = 0; r < ph; r++) memcpy(&blob[(size_t)r * pw], patch + (size_t)r * patch_pitch, (size_t)pw);
+    if (patch_mask) for (int r = 0; r < ph; r++) memcpy(&blob[pb + (size_t)r * pw], patch_mask + (size_t)r * pmask_pitch, (size_t)pw);
+    const size_t aoff = pb * (patch_mask ? 2 : 1);
+    if (area_mask) for (int r = 0; r < area_h; r++) memcpy(&blob[aoff + (size_t)r * area_w], area_mask + (size_t)r * amask_pitch, (size_t)area_w);
+    slam_match_job job;
+    job.frame = 0; job.level = 0; job.pw = pw; job.ph = ph;
+    job.patch_off = 0; job.pmask_off = patch_mask ? (int64_t)pb : -1;
+    job.ax = area_x; job.ay = area_y; job.aw = area_w; job.ah = area_h;
+    job.amask_off = area_mask ? (int64_t)aoff : -1;
+    job.stride = stride; job.use_exact_area_mask = use_exact_area_mask;
+    job.score_off = h_scores ? 0 : -1;
+    const size_t slen = h_scores ? (size_t)(area_w > 0 ? area_w : 0) * (size_t)(area_h > 0 ? area_h : 0) : 0;
+    // match_batch_host synchronises before it returns: the stack job and the local blob outlive their copies
+    return match_batch_host(ctx, pyr, &job, 1, blob.data(), blob.size(), slen ? h_scores : nullptr, slen, out);
 }
 
 extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs,
@@ -814,6 +835,7 @@ extern "C" int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const sl
             return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch: job %d: mask values must be 0 or 1", i);
     }
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t jb = sizeof(slam_track_job) * (size_t)njobs, rb = sizeof(slam_track_result) * (size_t)njobs;
     if ((rc = slam_stage_reserve(ctx, 0, jb)) || (rc = slam_stage_reserve(ctx, 1, blob_bytes + 16)) ||
         (rc = slam_stage_reserve(ctx, 2, rb)))
@@ -854,6 +876,7 @@ extern "C" int slam_hip_line_track_batch(slam_ctx* ctx, const slam_pyr* pyr, con
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t jb = sizeof(slam_line_job) * (size_t)njobs, rb = sizeof(slam_track_result) * (size_t)njobs;
     if ((rc = slam_stage_reserve(ctx, 0, jb)) || (rc = slam_stage_reserve(ctx, 1, blob_bytes + 16)) ||
         (rc = slam_stage_reserve(ctx, 2, rb)))
@@ -885,6 +908,7 @@ extern "C" int slam_hip_debug_score_formulas(slam_ctx* ctx, const uint64_t* cc, 
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "debug_score_formulas: bad arguments");
     if (n == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t b8 = (size_t)n * 8, b4 = (size_t)n * 4;
     int rc = slam_stage_reserve(ctx, 0, 3 * b8 + 2 * b4);
     if (rc != SLAM_HIP_OK) return rc;

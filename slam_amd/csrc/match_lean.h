@@ -87,10 +87,15 @@ struct LeanOut { int x, y; float response, dx, dy; bool ok; };
 #define LEAN_REJECT(code) ((void)0)
 #endif
 
-// Candidate slice counts; the cost model is instruction counts of the loops below.
-__device__ __forceinline__ int lean_pick_slices(int nunits, int nA, int nB, bool strips) {
-    const int ca = strips ? 9 : 4, cb = strips ? 14 : 6, cf = strips ? 30 : 16;
-    int best_s = 1, best_c = 0x7fffffff;
+// Slice count S and the per-slice trip counts: na all-kept entries per slice (the nA - na*S left over join the masked
+// part), nb masked entries per slice after padding.  The cost model is instruction counts of the loops below; every
+// division is by a compile-time constant.
+struct LeanSlices { int S, na, nb; };
+
+__device__ __forceinline__ LeanSlices lean_pick_slices(int nunits, int nA, int nB, bool strips) {
+    const int ca = strips ? 12 : 5, cb = strips ? 16 : 6, cf = strips ? 30 : 16;
+    LeanSlices best = {1, nA, nB};
+    int best_c = 0x7fffffff;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         constexpr int cand[8] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -99,9 +104,26 @@ __device__ __forceinline__ int lean_pick_slices(int nunits, int nA, int nB, bool
         const int a = nA / s;
         const int b = (nA - a * s + nB + s - 1) / s;
         const int c = passes * (a * ca + b * cb + cf);
-        if (c < best_c) { best_c = c; best_s = s; }
+        if (c < best_c) { best_c = c; best.S = s; best.na = a; best.nb = b; }
     }
-    return best_s;
+    return best;
+}
+
+// LDS bytes a level needs (INT_MAX: a shape this path does not take), with the window's column phase x0 & 3 at its
+// worst, so that the answer depends on sizes only and a walk can be turned away before its first level is searched.
+__device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized) {
+    const int G = (tw + 3) >> 2, NG = th * G;
+    const bool strips = step == 1;
+    const int cols = (aw + 6) >> 2;
+    const int tp = (cols + G - 1) | 1;
+    const int trows = ah + th - 1;
+    const int nacc = strips ? cols * ah * 4 : nx * ny;
+    const int cap = NG + LEAN_MAX_S + 8;
+    const int tile_bytes = (trows * tp * 8 + 15) & ~15;
+    const int raw_bytes = NG * 8 + (resized ? (G * 4 + th) * 8 : 0);
+    // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
+    if (tw > 256 || th > 256 || tw * th > 66051 || tp > 64 || nx * ny > 4096) return INT_MAX;
+    return ((nacc * 8 + 15) & ~15) + cap * 8 + ((cap * 4 + 15) & ~15) + max(tile_bytes, raw_bytes);
 }
 
 // accumulator index of the cell in tile column c (= o + x), row y, of a stride-1 search: strips of 4 columns run down
@@ -210,20 +232,16 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int G = (L.tw + 3) >> 2, NG = L.th * G;
     const int o = L.x0 & 3;
     const bool strips = L.step == 1;
-    const int nx = strips ? L.aw : (L.aw + L.step - 1) / L.step, ny = strips ? L.ah : (L.ah + L.step - 1) / L.step;
+    const int nx = strips ? L.aw : small_div_u(L.aw + L.step - 1, L.step), ny = strips ? L.ah : small_div_u(L.ah + L.step - 1, L.step);
     const int cols = (o + L.aw + 3) >> 2;                  // dword columns that hold a cell's first pixel
     const int tp = (cols + G - 1) | 1;                     // window positions per tile row, odd: see lean_accumulate
     const int trows = L.ah + L.th - 1;
     const int nunits = strips ? cols * L.ah : nx * ny;
     const int nacc = strips ? nunits * 4 : nunits;
     const int cap = NG + LEAN_MAX_S + 8;                   // room for the padding entries and for reads a few entries ahead
-    const int tile_bytes = (trows * tp * 8 + 15) & ~15;
-    const int raw_bytes = NG * 8 + (L.resized ? (G * 4 + L.th) * 8 : 0);
     const int acc_bytes = (nacc * 8 + 15) & ~15;
     const int list_bytes = cap * 8, marr_bytes = (cap * 4 + 15) & ~15;
-    const int need = acc_bytes + list_bytes + marr_bytes + max(tile_bytes, raw_bytes);
-    // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
-    if (need > lds_total || L.tw > 256 || L.th > 256 || L.tw * L.th > 66051 || tp > 64 || nx * ny > 4096) { LEAN_REJECT(100 + need); return out; }
+    if (lean_need(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized) > lds_total) { LEAN_REJECT(100); return out; }
     // tile rows are fetched as aligned dwords: a needed byte must not sit in a partial last dword of the image row
     if (L.x0 + L.aw + L.tw - 1 > (L.w & ~3)) { LEAN_REJECT(2); return out; }
     lds_u32* acc = reinterpret_cast<lds_u32*>(lds);
@@ -318,9 +336,9 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     STAMP(51);
 
     // ---- entry lists --------------------------------------------------------------------------------------------
-    const int S = lean_pick_slices(nunits, nA, nB, strips);
-    const int na = nA / S, nA1 = na * S;                    // all-kept entries per slice; the rest of them joins the masked part
-    const int nb = (nA - nA1 + nB + S - 1) / S, nB1 = nb * S;
+    const LeanSlices lsl = lean_pick_slices(nunits, nA, nB, strips);
+    const int S = lsl.S, na = lsl.na, nA1 = na * S;           // all-kept entries per slice; the rest of them joins the masked part
+    const int nb = lsl.nb, nB1 = nb * S;
     __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
     {
         int baseA = 0, baseB = nA;
@@ -355,7 +373,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             const unsigned dcol = (unsigned)((L.x0 - o) >> 2) + (unsigned)c;
             const unsigned g0 = min(dcol, lastd) * 4u, g1 = min(dcol + 1u, lastd) * 4u;
             const uint8_t* src = L.im + (unsigned long long)L.y0 * L.ipitch;
-            const int nit = (trows + rpp - 1) / rpp;       // wave-uniform
+            const int nit = (trows + rpp - 1) >> (6 - lg);   // wave-uniform
             for (int it = 0; it < nit; it += 4) {
                 unsigned d0[4], d1[4], ro[4];
 #pragma unroll

@@ -212,6 +212,7 @@ extern "C" int slam_hip_add_new_points(slam_ctx* ctx, const uint8_t* im, int w, 
     *nsel = 0;
     if (nkps == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t kb = sizeof(slam_keypoint) * (size_t)nkps;
     const size_t off_sorted = (kb + 255) / 256 * 256;
     const size_t off_occ = off_sorted + (kb + 255) / 256 * 256;

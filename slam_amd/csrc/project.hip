@@ -219,6 +219,7 @@ extern "C" int slam_hip_project_track_batch(slam_ctx* ctx, const slam_pyr* pyr, 
         tj[i].proj_off = wj[i].proj_off; tj[i].mask_off = wj[i].mask_off;
     }
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t wb = sizeof(slam_warp_job) * (size_t)njobs, tb = sizeof(slam_track_job) * (size_t)njobs;
     const size_t rb = sizeof(slam_track_result) * (size_t)njobs, sb = 4 * (size_t)njobs;
     const size_t o_t = (wb + 255) / 256 * 256, o_r = o_t + (tb + 255) / 256 * 256, o_s = o_r + (rb + 255) / 256 * 256;
@@ -261,6 +262,7 @@ extern "C" int slam_hip_project(slam_ctx* ctx, const uint8_t* descr, int dw, int
     job.dw = dw; job.dh = dh; job.ow = loc[2]; job.oh = loc[3];
     job.desc_off = 0; job.proj_off = 0; job.mask_off = (int64_t)npix;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t db = (size_t)dw * dh;
     const size_t o_desc = 256, o_out = o_desc + (db + 255) / 256 * 256;
     if ((rc = slam_stage_reserve(ctx, 0, o_out + 2 * npix + 16))) return rc;
@@ -384,6 +386,7 @@ extern "C" int slam_hip_match_lines_batch(slam_ctx* ctx, const slam_pyr* pyr, co
     for (int c = 0; c < ncircles; c++)
         if (circles[3 * c + 2] < 0) return slam_set_error(ctx, SLAM_HIP_EINVAL, "match_lines_batch: circle %d has a negative radius", c);
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t lb = sizeof(slam_line_job) * (size_t)njobs, db = sizeof(slam_disc_job) * (size_t)njobs;
     const size_t rb = sizeof(slam_track_result) * (size_t)njobs, cb = 12 * (size_t)ncircles;
     const size_t o_d = (lb + 255) / 256 * 256, o_r = o_d + (db + 255) / 256 * 256, o_c = o_r + (rb + 255) / 256 * 256;
@@ -514,6 +517,7 @@ extern "C" int slam_hip_track_ellipse_batch(slam_ctx* ctx, const slam_pyr* pyr, 
         max_pix = std::max(max_pix, e.w * e.h);
     }
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
     const size_t tb = sizeof(slam_track_job) * (size_t)njobs, eb = sizeof(slam_ellipse_job) * (size_t)njobs;
     const size_t rb = sizeof(slam_track_result) * (size_t)njobs;
     const size_t o_e = (tb + 255) / 256 * 256, o_r = o_e + (eb + 255) / 256 * 256;

@@ -418,10 +418,11 @@ extern "C" int slam_hip_pyramid_build(slam_ctx* ctx, slam_pyr* p, const uint8_t*
         if (e != hipSuccess) { (void)hipGetLastError(); return slam_set_error(ctx, SLAM_HIP_ENOMEM, "pyramid_build: hipMalloc(%zu): %s", need, hipGetErrorString(e)); }
         p->upload_bytes = need;
     }
-    for (int f = 0; f < p->nframes; f++)
-        SLAM_HIP_CHECK(ctx, hipMemcpy2DAsync(p->d_upload + (size_t)f * dstride, dpitch,
-                                             h_frames + (size_t)f * frame_stride, pitch,
-                                             (size_t)p->w, (size_t)p->h, hipMemcpyHostToDevice, ctx->stream));
+    for (int f = 0; f < p->nframes; f++) {
+        const int rcu = slam_upload_image(ctx, p->d_upload + (size_t)f * dstride, dpitch, h_frames + (size_t)f * frame_stride, pitch,
+                                          (size_t)p->w, (size_t)p->h, (size_t)f * dstride);
+        if (rcu != SLAM_HIP_OK) { (void)hipStreamSynchronize(ctx->stream); return rcu; }
+    }
     int rc = slam_hip_pyramid_build_d(ctx, p, p->d_upload, dpitch, dstride);
     if (rc != SLAM_HIP_OK) return rc;
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -12,6 +12,8 @@
 
 #include "slam_hip.h"
 
+struct slam_pyr;
+
 struct slam_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -25,6 +27,12 @@ struct slam_ctx {
     // queue of walk jobs the lean kernel leaves to the general one: a counter word, then the job indices
     int* d_queue = nullptr;
     size_t queue_jobs = 0;
+    // one-level pyramid reused by slam_hip_match_feature_in_area while the image size stays the same
+    slam_pyr* mfa_pyr = nullptr;
+    int mfa_w = 0, mfa_h = 0;
+    // pinned host staging for image uploads (slam_upload_image)
+    uint8_t* h_pin = nullptr;
+    size_t pin_bytes = 0;
     // growable device staging buffers used by the host-table entry points
     void* d_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_bytes[4] = {0, 0, 0, 0};
@@ -79,6 +87,13 @@ struct slam_pyr {
 int slam_set_error(slam_ctx* ctx, int code, const char* fmt, ...);
 int slam_stage_reserve(slam_ctx* ctx, int slot, size_t bytes);
 int slam_queue_reserve(slam_ctx* ctx, int njobs);
+// Queues the upload of `rows` rows of `width` bytes (host pitch spitch) to device rows of pitch dpitch.  A 2-D copy from
+// pageable memory is carried out row by row by the runtime (about 9 us per row); here the rows are packed into the
+// context's pinned buffer first and leave in one transfer.  The pinned buffer is reused by the next call: callers
+// synchronise the stream before they return (all host-image entry points do).  slot_off: byte offset inside the
+// pinned buffer for this image, so that one call can queue several.
+int slam_upload_image(slam_ctx* ctx, uint8_t* d_dst, size_t dpitch, const uint8_t* h_src, size_t spitch, size_t width, size_t rows,
+                      size_t slot_off);
 int slam_track_scratch_init(slam_ctx* ctx);
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
                       size_t blob_bytes, slam_track_result* d_out, int* queue);
@@ -90,6 +105,17 @@ int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* 
             return slam_set_error((ctx), SLAM_HIP_EHIP, "%s failed: %s (%s:%d)", #call,        \
                                   hipGetErrorString(e__), __FILE__, __LINE__);                 \
     } while (0)
+
+// Host-table entry points queue asynchronous copies from caller memory or from local vectors and synchronise before
+// they return; this guard makes every early (error) return wait for the stream as well, so that no copy is still
+// reading a buffer that is about to go out of scope.
+struct slam_stream_drain {
+    slam_ctx* ctx;
+    explicit slam_stream_drain(slam_ctx* c) : ctx(c) {}
+    ~slam_stream_drain() { (void)hipStreamSynchronize(ctx->stream); }
+    slam_stream_drain(const slam_stream_drain&) = delete;
+    slam_stream_drain& operator=(const slam_stream_drain&) = delete;
+};
 
 // Bilinear tap tables of cv::resize(INTER_LINEAR) for 8-bit images, computed on the host in
 // double/float exactly as OpenCV 2.4's resize() does (11-bit fixed-point coefficients).

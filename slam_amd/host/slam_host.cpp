@@ -26,6 +26,14 @@ void check(int rc, const char* what) {
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + slam_hip_last_error_string(context()));
 }
 
+// Live ImagePyramid mirrors of the calling thread: matchFeatureInArea looks an image up here, so that a search on a
+// pyramid level (lineFeature.cpp:125,154; feature.cpp:147 pass pyramid.images[i]) runs on the level that is already
+// resident on the device instead of uploading it again.
+std::vector<const ImagePyramid<byte>*>& live_pyramids() {
+    static thread_local std::vector<const ImagePyramid<byte>*> v;
+    return v;
+}
+
 }  // namespace slamhip
 
 ImagePyramid<byte>::ImagePyramid(const mati& imFullSize, const std::vector<float>& subs) : subsamples(subs) {
@@ -46,16 +54,57 @@ ImagePyramid<byte>::ImagePyramid(const mati& imFullSize, const std::vector<float
         pyr_ = nullptr;
         slamhip::check(rc, "ImagePyramid");
     }
+    slamhip::live_pyramids().push_back(this);
 }
 
 ImagePyramid<byte>::~ImagePyramid() {
+    std::vector<const ImagePyramid<byte>*>& v = slamhip::live_pyramids();
+    for (size_t i = 0; i < v.size(); i++)
+        if (v[i] == this) { v.erase(v.begin() + (long)i); break; }
     if (pyr_) slam_hip_pyramid_destroy(slamhip::context(), pyr_);
+}
+
+int ImagePyramid<byte>::levelOf(const mati& im) const {
+    for (size_t i = 0; i < images.size(); i++)
+        if (images[i].data == im.data && images[i].cols == im.cols && images[i].rows == im.rows && images[i].step == im.step)
+            return (int)i;
+    return -1;
 }
 
 cv::Point2i SLAM::matchFeatureInArea(const cv::Mat_<byte>& im, const cv::Mat_<byte>& patch,
                                      const cv::Mat_<byte>* patchMask, const cv::Rect& areaRect,
                                      const matb* areaMask, int stride, float& response, bool useExactAreaMask) {
     slam_match_result r;
+    // A whole level of a live pyramid (same buffer, same shape)?  Then search the resident level: the call uploads
+    // the patch and the masks only.  The levels are snapshots taken when the pyramid was built; nothing in the
+    // reference writes to them afterwards (imagePyramid.hpp:15-30), and writes to `images` would not be seen here.
+    const std::vector<const ImagePyramid<byte>*>& live = slamhip::live_pyramids();
+    for (size_t k = 0; k < live.size(); k++) {
+        const int level = live[k]->levelOf(im);
+        if (level < 0) continue;
+        if (patch.cols < 1 || patch.rows < 1 || stride < 1) break;          // let the generic entry point report it
+        const size_t pb = (size_t)patch.cols * patch.rows;
+        const size_t ab = areaMask ? (size_t)(areaRect.width > 0 ? areaRect.width : 0) * (size_t)(areaRect.height > 0 ? areaRect.height : 0) : 0;
+        if (areaMask && (areaMask->cols != areaRect.width || areaMask->rows != areaRect.height)) break;
+        if (patchMask && (patchMask->cols != patch.cols || patchMask->rows != patch.rows)) break;
+        std::vector<uint8_t> blob(pb * (patchMask ? 2 : 1) + ab + 1);
+        for (int y = 0; y < patch.rows; y++) std::memcpy(&blob[(size_t)y * patch.cols], patch.ptr(y), (size_t)patch.cols);
+        if (patchMask) for (int y = 0; y < patch.rows; y++) std::memcpy(&blob[pb + (size_t)y * patch.cols], patchMask->ptr(y), (size_t)patch.cols);
+        const size_t aoff = pb * (patchMask ? 2 : 1);
+        if (areaMask) for (int y = 0; y < areaMask->rows; y++) std::memcpy(&blob[aoff + (size_t)y * areaMask->cols], areaMask->ptr(y), (size_t)areaMask->cols);
+        slam_match_job job;
+        std::memset(&job, 0, sizeof(job));
+        job.frame = 0; job.level = level; job.pw = patch.cols; job.ph = patch.rows;
+        job.patch_off = 0; job.pmask_off = patchMask ? (int64_t)pb : -1;
+        job.ax = areaRect.x; job.ay = areaRect.y; job.aw = areaRect.width; job.ah = areaRect.height;
+        job.amask_off = areaMask ? (int64_t)aoff : -1;
+        job.stride = stride; job.use_exact_area_mask = useExactAreaMask ? 1 : 0;
+        job.score_off = -1;
+        slamhip::check(slam_hip_match_batch(slamhip::context(), live[k]->device(), &job, 1, blob.data(), blob.size(), &r), "matchFeatureInArea");
+        if (r.status != SLAM_HIP_OK) throw std::invalid_argument("matchFeatureInArea: job rejected by the device");
+        response = r.response;
+        return cv::Point2i(r.x, r.y);
+    }
     slamhip::check(slam_hip_match_feature_in_area(
                        slamhip::context(), im.data, im.cols, im.rows, im.step, patch.data, patch.cols, patch.rows,
                        patch.step, patchMask ? patchMask->data : nullptr, patchMask ? patchMask->step : 0,

@@ -30,6 +30,11 @@ slam_ctx* context();
 void check(int rc, const char* what);
 }  // namespace slamhip
 
+template <typename imtype> class ImagePyramid;
+namespace slamhip {
+std::vector<const ImagePyramid<unsigned char>*>& live_pyramids();
+}
+
 // imagePyramid.hpp:9-34.  `images` are host copies of the levels (what reference code indexes);
 // the levels also stay resident on the device for the search calls below.
 template <typename imtype> class ImagePyramid;
@@ -45,6 +50,8 @@ public:
     ImagePyramid& operator=(const ImagePyramid&) = delete;
     size_t nSubs() const { return subsamples.size(); }
     const slam_pyr* device() const { return pyr_; }
+    // index of the level whose host image `im` is (same buffer and shape), or -1
+    int levelOf(const mati& im) const;
 private:
     slam_pyr* pyr_ = nullptr;
 };

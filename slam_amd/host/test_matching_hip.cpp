@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <cmath>
 
 #include "slam_host.hpp"
 #include "slam_oracle.h"
@@ -342,6 +344,84 @@ static bool test_match_lines() {
     return true;
 }
 
+// LineFeature::track's own calls (lineFeature.cpp:125-127 and :154-156) made on pyramid.images[i], as the reference's
+// unchanged CPU code makes them: they must run on the levels that are resident on the device (no upload of the frame)
+// and return what the oracle returns.  Also prints the per-call cost of that route next to the route a foreign image takes.
+static bool test_line_calls_on_resident_levels() {
+    const int w = 640, h = 480;
+    matb im0(h, w), im(h, w);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            im0(y, x) = (byte)(((x / 11) * 53 + (y / 6) * 29 + ((x * 5 + y * 3) % 19)) & 0xFF);
+            const int xs = x - 3, ys = y + 2;
+            im(y, x) = (byte)(((xs / 11) * 53 + (ys / 6) * 29 + ((xs * 5 + ys * 3) % 19)) & 0xFF);
+        }
+    std::vector<float> subs;
+    subs.push_back(1.f); subs.push_back(2.f);
+    ImagePyramid<byte> pyramid(im, subs);
+    uint8_t* lev[2]; int lw[2], lh[2];
+    std::vector<std::vector<uint8_t> > store(2);
+    for (int i = 0; i < 2; i++) {
+        so_pyramid_level_size(w, h, subs[i], &lw[i], &lh[i]);
+        store[i].resize((size_t)lw[i] * lh[i]);
+        lev[i] = store[i].data();
+    }
+    so_pyramid_build(im.data, w, h, (ptrdiff_t)im.step, 2, subs.data(), lev);
+    if (pyramid.levelOf(pyramid.images[1]) != 1 || pyramid.levelOf(pyramid.images[1].clone()) != -1) { printf("levelOf\n"); return false; }
+    const int stride = 2;
+    for (int k = 0; k < 8; k++) {
+        const int cx = 90 + 55 * k, cy = 100 + 32 * k, half = 20;
+        const matb descr = im0(Rect(cx - half, cy - half, 2 * half + 1, 2 * half + 1)).clone();
+        // lineFeature.cpp:124: descriptor resized to the coarsest level (cv::resize, done by the caller on the CPU)
+        const int cw = (int)std::lround(descr.cols * 0.5), ch = (int)std::lround(descr.rows * 0.5);
+        matb cdescr(ch, cw);
+        so_resize_u8_linear(descr.data, descr.cols, descr.rows, (ptrdiff_t)descr.step, cdescr.data, cw, ch, (ptrdiff_t)cdescr.step);
+        const int tx = (cx + 3) / 2, ty = (cy - 2) / 2;
+        const Rect area(k == 7 ? -9 : tx - 14, k == 7 ? -7 : ty - 9, 30, 20);       // the last one hangs over the image corner
+        matb amask(area.height, area.width);
+        std::vector<int> circ;
+        for (int b = 0; b < 5; b++) { circ.push_back(4 + 5 * b + (k % 3)); circ.push_back(5 + 2 * b); circ.push_back(2 + (b + k) % 4); }
+        so_disc_mask(area.width, area.height, circ.data(), 5, amask.data);
+        float r1 = 0.f;
+        const Point2i p1 = SLAM::matchFeatureInArea(pyramid.images[1], cdescr, NULL, area, &amask, stride, r1);            // lineFeature.cpp:125-127
+        so_match_out o1;
+        so_match_feature_in_area(lev[1], lw[1], lh[1], lw[1], cdescr.data, cw, ch, (ptrdiff_t)cdescr.step, NULL, 0, area.x, area.y, area.width,
+                                 area.height, amask.data, (ptrdiff_t)amask.step, stride, 0, NULL, &o1);
+        if (p1.x != o1.x || p1.y != o1.y || std::memcmp(&r1, &o1.response, 4) != 0) {
+            printf("coarse call %d: HIP (%d,%d,%.9g) oracle (%d,%d,%.9g)\n", k, p1.x, p1.y, r1, o1.x, o1.y, o1.response);
+            return false;
+        }
+        const Rect fine(2 * p1.x - 2, 2 * p1.y - 2, 5, 5);                                                                  // lineFeature.cpp:150-152
+        float r0 = 0.f;
+        const Point2i p0 = SLAM::matchFeatureInArea(pyramid.images[0], descr, NULL, fine, NULL, 1, r0);                      // lineFeature.cpp:154-156
+        so_match_out o0;
+        so_match_feature_in_area(lev[0], lw[0], lh[0], lw[0], descr.data, descr.cols, descr.rows, (ptrdiff_t)descr.step, NULL, 0, fine.x, fine.y, 5, 5,
+                                 NULL, 0, 1, 0, NULL, &o0);
+        if (p0.x != o0.x || p0.y != o0.y || std::memcmp(&r0, &o0.response, 4) != 0) {
+            printf("fine call %d: HIP (%d,%d,%.9g) oracle (%d,%d,%.9g)\n", k, p0.x, p0.y, r0, o0.x, o0.y, o0.response);
+            return false;
+        }
+    }
+    // per-call cost: the resident level against an equal image that belongs to no pyramid (uploaded on every call)
+    const matb foreign = pyramid.images[0].clone();
+    const matb descr = im0(Rect(300, 200, 41, 41)).clone();
+    const Rect win(301, 196, 5, 5);
+    float r = 0.f, rf = 0.f;
+    const int reps = 200;
+    struct timespec t0, t1, t2;
+    SLAM::matchFeatureInArea(pyramid.images[0], descr, NULL, win, NULL, 1, r);
+    SLAM::matchFeatureInArea(foreign, descr, NULL, win, NULL, 1, rf);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < reps; i++) SLAM::matchFeatureInArea(pyramid.images[0], descr, NULL, win, NULL, 1, r);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int i = 0; i < reps; i++) SLAM::matchFeatureInArea(foreign, descr, NULL, win, NULL, 1, rf);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    const double us_res = ((t1.tv_sec - t0.tv_sec) * 1e9 + (t1.tv_nsec - t0.tv_nsec)) / reps / 1e3;
+    const double us_for = ((t2.tv_sec - t1.tv_sec) * 1e9 + (t2.tv_nsec - t1.tv_nsec)) / reps / 1e3;
+    printf("matchFeatureInArea per call, 640x480 level, 41x41 patch, 5x5 window: resident level %.1f us, foreign image %.1f us\n", us_res, us_for);
+    return std::memcmp(&r, &rf, 4) == 0;
+}
+
 int main(int argc, char* argv[]) {
     const int nTrials = argc > 1 ? std::atoi(argv[1]) : 100;
     int failed = 0;
@@ -355,6 +435,7 @@ int main(int argc, char* argv[]) {
         DO_TEST("test_pyramid_track_keypoints", test_pyramid_track_keypoints());
         DO_TEST("test_project_track", test_project_track());
         DO_TEST("test_match_lines", test_match_lines());
+        DO_TEST("test_line_calls_resident", test_line_calls_on_resident_levels());
     } catch (const std::exception& e) {
         printf("exception: %s\n", e.what());
         return 2;

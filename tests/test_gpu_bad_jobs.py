@@ -33,7 +33,7 @@ def test_bad_match_and_track_jobs_are_rejected(ctx, oracle):
                 setattr(j, k, v)
             return j
         bad = [dict(frame=1), dict(frame=-1), dict(level=2), dict(level=-1), dict(pw=0), dict(ph=-3), dict(patch_off=100),
-               dict(patch_off=-5), dict(pmask_off=82), dict(stride=0), dict(stride=-2), dict(amask_off=0, aw=20, ah=20),
+               dict(patch_off=-5), dict(pmask_off=82), dict(stride=0), dict(stride=-2), dict(stride=(1 << 20) + 1), dict(stride=0x7fffffff), dict(amask_off=0, aw=20, ah=20),
                dict(pw=1 << 20), dict(aw=1 << 30, ah=1 << 30)]
         empty = [dict(aw=0), dict(ah=-1)]                # an empty area is answered like one that misses the image (matching.cpp:26-30)
         jobs = [mjob()] + [mjob(**b) for b in bad] + [mjob(**b) for b in empty] + [mjob(ax=71)]
@@ -102,6 +102,9 @@ def test_host_entry_points_reject_unusable_arguments(ctx):
         assert L.slam_hip_match_batch(ctx.handle, pyr, C.byref(j), 1, p.ctypes.data, p.size, C.byref(res)) == capi.EINVAL
     finally:
         L.slam_hip_pyramid_destroy(ctx.handle, pyr)
-    assert L.slam_hip_set_match_lds(ctx.handle, 1000) == capi.EINVAL
-    assert L.slam_hip_set_match_lds(ctx.handle, 65536) == capi.EINVAL      # with the kernels' static LDS it would pass 64 KB
-    assert L.slam_hip_set_match_lds(ctx.handle, 10240) == 0      # back to the default
+    with api.Context(0) as own:                          # a context of its own: the shared one keeps the shipped LDS split
+        assert L.slam_hip_set_match_lds(own.handle, 1000) == capi.EINVAL
+        assert L.slam_hip_set_match_lds(own.handle, 65536) == capi.EINVAL      # with the kernels' static LDS it would pass 64 KB
+        assert L.slam_hip_set_match_lds(own.handle, 10240) == 0
+        assert L.slam_hip_set_walk_lds(own.handle, 100) == capi.EINVAL
+        assert L.slam_hip_set_walk_lds(own.handle, 16384) == 0

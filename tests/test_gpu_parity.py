@@ -365,7 +365,7 @@ def test_track_matches_oracle(ctx, oracle, w, h, subs, nfeat, tsize, min_found):
         pyr.close()
 
 
-@pytest.mark.parametrize("lds", [4096, 8192, 32768, 64512])
+@pytest.mark.parametrize("lds", [4096, 8192, 9216, 12288, 32768, 64512])
 def test_results_do_not_depend_on_the_lds_budget(oracle, lds):
     """The LDS a job may use only changes how its work is cut into blocks and chunks (slam_hip_set_match_lds):
     walks, single searches with score maps and line-style searches give the oracle's results at every budget."""
@@ -374,6 +374,7 @@ def test_results_do_not_depend_on_the_lds_budget(oracle, lds):
     f0, f1 = synth.frame(w, h, 12), synth.frame(w, h, 12, shift)
     with api.Context(0) as c:
         api.capi.check(c.handle, api.capi.lib().slam_hip_set_match_lds(c.handle, lds))
+        api.capi.check(c.handle, api.capi.lib().slam_hip_set_walk_lds(c.handle, lds))      # the lean walk kernel's budget too
         jobs = _c2_like_jobs(rng, w, h, 24, 21, f0, shift) + _c2_like_jobs(rng, w, h, 4, 81, f0, shift)
         pyr = api.ImagePyramid(c, f1, subs)
         try:
