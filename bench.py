@@ -241,7 +241,14 @@ def load_traffic():
     if not os.path.exists(TRAFFIC_FILE):
         return {}
     with open(TRAFFIC_FILE) as fh:
-        return json.load(fh)
+        return json.load(fh).get("kernels", {})
+
+
+def traffic_of(traffic, *keys):
+    """Sum of the profiled HBM bytes per launch of the kernels `name@workgroups`; None when one of them is not in the profile."""
+    if not all(k in traffic for k in keys):
+        return None
+    return sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)
 
 
 def timed(stream, fn, steps, warm=3):
@@ -258,7 +265,7 @@ def timed(stream, fn, steps, warm=3):
 
 def search_report(name, kernel, ms, positions, alg_bytes, macs, traffic, extra=None):
     ach = alg_bytes / (ms * 1e-3) / 1e9
-    tr = traffic.get(name, {}).get("hbm_bytes_per_launch")
+    tr = traffic_of(traffic, *name.split("+"))
     out = {"value": positions / (ms * 1e-3), "unit": "positions/s", "ms": ms,
            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes_per_launch": int(alg_bytes),
@@ -304,12 +311,13 @@ def fast_leg(api, capi, ctx, stream, dev, args, traffic):
         parity = "frame 0: %d corners, list identical to the oracle's" % len(ref)
     ms = timed(stream, go, max(5, args.steps))
     alg = w * h * nfr + 12 * int(np.minimum(cnt, cap).sum())
-    tr = sum(traffic.get(k, {}).get("hbm_bytes_per_launch", 0) for k in ("fast_tile_kernel", "fast_scan_kernel", "fast_scatter_kernel"))
+    p_ntx, p_nty = (w + 247) // 248, (h + 29) // 30                # the tile kernel's grid
+    tr = traffic_of(traffic, "fast_tile_kernel@%d" % (p_ntx * p_nty * nfr), "fast_scan_kernel@%d" % nfr, "fast_scatter_kernel@%d" % (p_ntx * p_nty * nfr))
     return {"workload": "C4: %d frames %dx%d, FAST-9-16 threshold %d + non-max suppression" % (nfr, w, h, thr),
             "value": w * h * nfr / (ms * 1e-3), "unit": "px/s", "ms": ms, "corners_per_frame": float(cnt.mean()),
             "roofline": {"bound": "hbm", "kernel": "fast_tile_kernel+fast_scan_kernel+fast_scatter_kernel", "achieved": alg / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": tr or None, "algorithmic_bytes_per_launch": alg},
+                         "traffic": tr, "algorithmic_bytes_per_launch": alg},
             "parity": parity}
 
 
@@ -391,7 +399,7 @@ def c1_leg(api, capi, ctx, stream, dev, args, traffic):
     ms = timed(stream, go, max(5, args.steps))
     positions = float(cells[k_idx, mode].sum())
     alg = float(byts[k_idx, mode].sum())
-    out = search_report("c1_match_kernel", "match_kernel", ms, positions, alg, positions * 2 * ts * ts, traffic,
+    out = search_report("match_kernel@%d" % len(jobs), "match_kernel", ms, positions, alg, positions * 2 * ts * ts, traffic,
                         {"workload": "C1: %dx%d, %d features/frame, %dx%d templates, %dx%d windows, stride 1, four mask modes mixed; %d frames"
                                      % (w, h, nfeat, ts, ts, win, win, nfr), "jobs": len(jobs), "parity": parity})
     pyr.close()
@@ -479,7 +487,7 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
     macs = float((ran * c3 * 2 * tw3 * tw3 + cum_m[np.maximum(lr - 1, 0)]).sum())
     ms = timed(stream, go, max(5, args.steps))
     ms_p = timed(stream, lambda: pyr.rebuild_d(d_fr.data_ptr(), w, w * h), max(5, args.steps))
-    out = search_report("c3_track_kernel", "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
+    out = search_report("track_lean_kernel@%d+track_kernel@4096" % len(jobs), "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
                         {"workload": "C3: %dx%d, %d features/frame, %dx%d masked templates, pyramid {1,2,4,8}, ellipse windows "
                                      "(area masks) on the coarsest level, stride 3; %d frames" % (w, h, nfeat, ts, ts, nfr),
                          "jobs": len(jobs), "pyramid_ms": ms_p, "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
@@ -557,7 +565,7 @@ def line_leg(api, capi, ctx, stream, dev, args, traffic):
                   (aw + tc - 1) * (ah + tc - 1) + tc * tc + aw * ah + 20 + (5 + ds - 1) ** 2 + ds * ds + 20], np.float64)
     m = np.array([0, 2.0 * aw * ah * tc * tc, 2.0 * aw * ah * tc * tc + 2.0 * 25 * ds * ds])
     ms = timed(stream, go, max(5, args.steps))
-    out = search_report("line_track_kernel", "line_track_kernel", ms, float(c[lr].sum()), float(b[lr].sum()), float(m[lr].sum()), traffic,
+    out = search_report("line_track_kernel@%d" % len(jobs), "line_track_kernel", ms, float(c[lr].sum()), float(b[lr].sum()), float(m[lr].sum()), traffic,
                         {"workload": "line walk: %dx%d, %d lines/frame, %dx%d descriptors, pyramid {1,2}, stride 2, %dx%d disc-union "
                                      "area on the coarsest level; %d frames" % (w, h, nline, ds, ds, aw, ah, nfr),
                          "jobs": len(jobs), "refined_at_full_resolution": float((lr == 2).mean()), "parity": parity})
@@ -709,8 +717,7 @@ def main(argv=None):
 
     if rank == 0:
         traffic = load_traffic()
-        tk = traffic.get("track_kernel", {})
-        tr = tk.get("hbm_bytes_per_launch") if traffic.get("sequences_per_gpu") == nseq else None
+        tr = traffic_of(traffic, "track_lean_kernel@%d" % (8 * ((njobs + 7) // 8)), "track_kernel@%d" % min(njobs, 4096))
         ach = alg_bytes / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "NCC patch-match positions/sec (pyramid build + coarse-to-fine template search)",

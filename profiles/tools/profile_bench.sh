@@ -5,7 +5,7 @@
 #   calib_*/ the same two counters on kernels with known byte counts (profiles/tools/pmc_calib.hip)
 # usage: profiles/tools/profile_bench.sh <tag>
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -497,7 +497,12 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(sla
                                                         slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
-    const int j = blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own.  Workgroup b takes job
+    // (b % 8) * ceil(njobs / 8) + b / 8, so that every XCD walks one contiguous eighth of the job table: the features
+    // of a frame - whose image tiles share 128-byte lines, most of all on the coarse levels - meet in one L2 back to
+    // back.  Placement is a matter of speed only: any assignment of jobs to workgroups gives the same results.
+    const int per = (njobs + 7) >> 3;
+    const int j = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
     if (j >= njobs) return;
     const slam_track_job job = jobs[j];
     slam_track_result r;
@@ -783,7 +788,7 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
                       size_t blob_bytes, slam_track_result* d_out, int* queue) {
     SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(track_lean_kernel, dim3(njobs), dim3(SLAM_WG), ctx->lean_lds_bytes, ctx->stream, pyr->dev, d_jobs, njobs,
+    hipLaunchKernelGGL(track_lean_kernel, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), ctx->lean_lds_bytes, ctx->stream, pyr->dev, d_jobs, njobs,
                        d_blob, (unsigned long long)blob_bytes, d_out, ctx->lean_lds_bytes, queue);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     // enough workgroups to fill the chip if everything was queued, few enough to start and end in microseconds if nothing was
