@@ -16,6 +16,7 @@
 // Kernel 3 (fast_scatter_kernel): copies every segment to its place in the output as keypoints.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "slam_internal.h"
 
@@ -28,8 +29,7 @@ constexpr int FAST_PPITCH = FAST_CW + 8;        // pixel tile pitch: 4 more colu
 constexpr int FAST_TH = 30;                     // output rows per tile
 constexpr int FAST_SR = FAST_TH + 2;            // score rows: one halo row above and below; 8 per wavefront
 constexpr int FAST_PR = FAST_TH + 8;            // pixel rows
-constexpr int FAST_HALF = FAST_SR / 8;          // score rows a wavefront tests before it scores their candidates
-constexpr int FAST_LIST = FAST_HALF * FAST_CW;  // candidate slots per wavefront
+constexpr int FAST_LIST = 768;                  // candidate slots per wavefront; a row adds at most 2 * FAST_CW (one per pixel and polarity)
 
 struct FastPlan {
     int ntx, nty;     // tiles per row / column of tiles
@@ -82,18 +82,18 @@ __device__ __forceinline__ fast_u2 ring_pair(unsigned a, unsigned b, unsigned c,
     return __builtin_bit_cast(fast_u2, r);
 }
 
-// max over the 16 arcs of 9 contiguous ring pixels of the arc minimum of (v - ring) [low half] and
-// of (ring - v) [high half]: the two "A" values of cv::FAST's cornerScore, by window doubling.
-__device__ __forceinline__ void fast_arc_scores(const fl_u8* p, int pitch, int& a_dark, int& a_bright) {
-    const int v = p[0];
+// cv::FAST's cornerScore "A" value of two candidates at once, one per 16-bit half: max over the 16 arcs of 9 contiguous
+// ring pixels of the arc minimum of (ring - v) for a candidate of the bright polarity, of (v - ring) for the dark one.
+// A dark candidate is turned into a bright one by complementing its bytes (255 - x = x ^ 0xFF keeps differences):
+// xm holds 0xFF in the halves of dark candidates.  Window doubling: minima over 2, 4, 8 neighbours, then 9.
+__device__ __forceinline__ fast_s2 fast_arc_scores2(const fl_u8* p1, const fl_u8* p2, int pitch, unsigned xm) {
+    const unsigned V = ((unsigned)p1[0] | ((unsigned)p2[0] << 16)) ^ xm;
     fast_s2 e[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        // (v - r, r - v) from the pair (v, r) with one packed subtraction whose operands are the pair and its swap
-        const unsigned vr = (unsigned)v | ((unsigned)p[ring_dy(k) * pitch + ring_dx(k)] << 16);
-        unsigned d;
-        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(d) : "v"(vr));
-        e[k] = __builtin_bit_cast(fast_s2, d);
+        const int o = ring_dy(k) * pitch + ring_dx(k);
+        const unsigned R = ((unsigned)p1[o] | ((unsigned)p2[o] << 16)) ^ xm;
+        e[k] = __builtin_bit_cast(fast_s2, R) - __builtin_bit_cast(fast_s2, V);
     }
     fast_s2 m2[16], m4[16], m8[16];
 #pragma unroll
@@ -105,7 +105,40 @@ __device__ __forceinline__ void fast_arc_scores(const fl_u8* p, int pitch, int& 
     fast_s2 best = fast_s2{(short)-512, (short)-512};
 #pragma unroll
     for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], e[(k + 8) & 15]));
-    a_dark = best.x; a_bright = best.y;
+    return best;
+}
+
+// Opposite-pair test of a lane's 4 adjacent pixels (the window rows dy = -3..3 are A/B/Cw[0..6]: dwords at pixel bytes
+// 4*lane, +4, +8).  Two pixels per operation: pixels j = 0 and 2 as 16-bit halves, then pixels 1 and 3.  A 9-long arc holds
+// a member of every opposite ring pair, so for a bright arc every pair has a member brighter than v+t (min over pairs of
+// the pair maximum > v+t), for a dark arc every pair has a member darker than v-t (max over pairs of the pair minimum < v-t).
+__device__ __forceinline__ void fast_pair_test(const unsigned* A, const unsigned* B, const unsigned* Cw, int t, unsigned& candB, unsigned& candD) {
+    fast_u2 mn_of_mx[2], mx_of_mn[2];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            const fast_u2 r0 = ring_pair(A[3 + ring_dy(k)], B[3 + ring_dy(k)], Cw[3 + ring_dy(k)], ring_dx(k), o);
+            const fast_u2 r1 = ring_pair(A[3 + ring_dy(k + 8)], B[3 + ring_dy(k + 8)], Cw[3 + ring_dy(k + 8)], ring_dx(k + 8), o);
+            const fast_u2 mx = __builtin_elementwise_max(r0, r1), mn = __builtin_elementwise_min(r0, r1);
+            mn_of_mx[o] = k == 0 ? mx : __builtin_elementwise_min(mn_of_mx[o], mx);
+            mx_of_mn[o] = k == 0 ? mn : __builtin_elementwise_max(mx_of_mn[o], mn);
+        }
+    }
+    const fast_u2 T = fast_u2{(unsigned short)t, (unsigned short)t};
+    const fast_u2 one = fast_u2{(unsigned short)1, (unsigned short)1};
+    unsigned nb[2], nd[2];                               // 0 / 1 per 16-bit half: pixel (o, o + 2) is a bright / dark candidate
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        const fast_u2 v = ring_pair(A[3], B[3], Cw[3], 0, o);
+        // saturating differences are non-zero exactly when the comparison holds
+        nb[o] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_sub_sat(mn_of_mx[o], v + T), one));
+        nd[o] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_sub_sat(v, mx_of_mn[o] + T), one));
+    }
+    // halves (pixel 0 | pixel 1 << 1, pixel 2 | pixel 3 << 1) -> bits 0..3
+    const unsigned pb = nb[0] | (nb[1] << 1), pd = nd[0] | (nd[1] << 1);
+    candB = (pb & 3u) | ((pb >> 14) & 12u);
+    candD = (pd & 3u) | ((pd >> 14) & 12u);
 }
 
 // Inclusive prefix sum over the 64 lanes with DPP moves: four row_shr steps inside each row of 16
@@ -121,7 +154,7 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
 }
 
 
-__global__ __launch_bounds__(FAST_WG) void fast_tile_kernel(
+__global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
     const uint8_t* __restrict__ frames, int w, int h, long long pitch, long long frame_stride,
     int threshold, int nonmax, int ntx, unsigned* __restrict__ scratch) {
     __shared__ __attribute__((aligned(16))) unsigned char px_s[FAST_PR * FAST_PPITCH];    // pixels
@@ -138,41 +171,53 @@ __global__ __launch_bounds__(FAST_WG) void fast_tile_kernel(
     unsigned* fs = scratch + (size_t)frame * fast_frame_words(h, ntx);
     const bool aligned = ((reinterpret_cast<unsigned long long>(frames) | (unsigned long long)pitch | (unsigned long long)frame_stride) & 3ull) == 0;
     const int t = threshold;
+    // diagnostic runs (SLAM_HIP_FAST_DIAG, never set in production) leave out a phase; run-time bits, so that the
+    // compiler cannot drop the phases that feed the skipped one: 1 = no pair test, 2 = no scoring, 4 = no suppression
+    const int diag = nonmax >> 8;
+    nonmax &= 1;
 
     {   // zero the score tile
         fl_u32* z = (fl_u32*)sc;
 #pragma unroll
         for (int i = 0; i < FAST_SR * FAST_CW / 4 / FAST_WG; i++) z[tid + i * FAST_WG] = 0u;
     }
-    // ---- stage pixels: tile row r <-> image row y0 - 4 + r, tile byte c <-> image column cx0 - 8 + c
-    // (loads of a batch are all issued before the first LDS write: one memory round trip per batch)
+    // ---- stage pixels: tile row r <-> image row y0 - 4 + r, tile byte c <-> image column cx0 - 8 + c.  A wavefront
+    // takes every fourth row; lane l carries dword l of the row and lanes 0 and 1 also dwords 64 and 65.  Column
+    // bounds depend on the lane only and are settled before the row loop; the loads of all of a wavefront's rows are
+    // issued before the first LDS write (one memory round trip).
     {
-        constexpr int NB = 10;
-        constexpr int ndw = FAST_PR * (FAST_PPITCH / 4);
-        for (int base = tid; base < ndw; base += FAST_WG * NB) {
-            unsigned v[NB];
+        constexpr int RW = (FAST_PR + 3) / 4;                    // rows per wavefront
+        constexpr int DW = FAST_PPITCH / 4;                      // dwords per tile row (66)
+        const int xa = cx0 - 8 + 4 * lane, xb = xa + 256;        // image column of the lane's dword, and of its second one
+        const bool in_a = aligned && xa >= 0 && xa + 3 < w, in_b = aligned && lane < DW - 64 && xb >= 0 && xb + 3 < w;
+        const bool edge_a = !in_a && xa + 3 >= 0 && xa < w, edge_b = !in_b && lane < DW - 64 && xb + 3 >= 0 && xb < w;
+        unsigned va[RW], vb[RW];
 #pragma unroll
-            for (int u = 0; u < NB; u++) {
-                const int i = base + u * FAST_WG;
-                v[u] = 0;
-                if (i < ndw) {
-                    const int r = i / (FAST_PPITCH / 4), c = i - r * (FAST_PPITCH / 4);
-                    const int y = y0 - 4 + r, x = cx0 - 8 + 4 * c;
-                    if (y >= 0 && y < h && x + 3 >= 0 && x < w) {
-                        const uint8_t* src = im + (long long)y * pitch + x;
-                        if (aligned && x >= 0 && x + 3 < w) v[u] = *reinterpret_cast<const unsigned*>(src);
-                        else {
+        for (int q = 0; q < RW; q++) {
+            const int r = wid + 4 * q, y = y0 - 4 + r;
+            va[q] = 0; vb[q] = 0;
+            if (r < FAST_PR && y >= 0 && y < h) {                // wave-uniform
+                const uint8_t* src = im + (long long)y * pitch;
+                if (in_a) va[q] = *reinterpret_cast<const unsigned*>(src + xa);
+                else if (edge_a) {
 #pragma unroll
-                            for (int b = 0; b < 4; b++)
-                                if (x + b >= 0 && x + b < w) v[u] |= (unsigned)src[b] << (8 * b);
-                        }
-                    }
+                    for (int b2 = 0; b2 < 4; b2++)
+                        if (xa + b2 >= 0 && xa + b2 < w) va[q] |= (unsigned)src[xa + b2] << (8 * b2);
+                }
+                if (in_b) vb[q] = *reinterpret_cast<const unsigned*>(src + xb);
+                else if (edge_b) {
+#pragma unroll
+                    for (int b2 = 0; b2 < 4; b2++)
+                        if (xb + b2 >= 0 && xb + b2 < w) vb[q] |= (unsigned)src[xb + b2] << (8 * b2);
                 }
             }
+        }
 #pragma unroll
-            for (int u = 0; u < NB; u++) {
-                const int i = base + u * FAST_WG;
-                if (i < ndw) reinterpret_cast<fl_u32*>(px)[i] = v[u];
+        for (int q = 0; q < RW; q++) {
+            const int r = wid + 4 * q;
+            if (r < FAST_PR) {
+                reinterpret_cast<fl_u32*>(px)[r * DW + lane] = va[q];
+                if (lane < DW - 64) reinterpret_cast<fl_u32*>(px)[r * DW + 64 + lane] = vb[q];
             }
         }
     }
@@ -182,87 +227,74 @@ __global__ __launch_bounds__(FAST_WG) void fast_tile_kernel(
     // score column c <-> image column cx0 - 4 + c <-> pixel byte c + 4
     constexpr int rows_per_wave = FAST_SR / 4;
     fl_u16* mylist = lists + wid * FAST_LIST;
-    for (int half = 0; half < rows_per_wave; half += FAST_HALF) {
-    int n = 0;                                                   // candidates of this wavefront in these rows
-    for (int rr = half; rr < half + FAST_HALF; rr++) {
-        const int ry = wid * rows_per_wave + rr;
-        const int y = y0 - 1 + ry;
-        if (y < 3 || y >= h - 3) continue;                       // wave-uniform
+    // Phase 1 proper: the pair test of the wavefront's 8 score rows.  The 14 window rows they span are read once (8
+    // score rows share them); every lane keeps one byte per row: bits 0..3 = its pixels that are bright candidates,
+    // bits 4..7 = dark candidates.
+    unsigned cand_lo = 0, cand_hi = 0;                           // rows 0..3 and 4..7, one byte each
+    {
+        const int ry0 = wid * rows_per_wave;
         const int x0 = cx0 - 4 + 4 * lane;                       // image column of the first of the lane's 4 pixels
-        unsigned cand = 0;
-#ifdef FAST_DIAG_SKIP_P1
-        if (x0 < -w) {
-#else
-        if (x0 < w - 3 && x0 + 3 >= 3) {
-#endif
-            // window rows dy = -3..3: dwords at pixel bytes 4*lane, +4, +8 (score columns 4*lane-4 .. 4*lane+7)
-            unsigned A[7], B[7], Cw[7];
+        unsigned inside = 0;                                     // only pixels with a full ring inside the image are tested
 #pragma unroll
-            for (int d = 0; d < 7; d++) {
-                const fl_u32* row = reinterpret_cast<const fl_u32*>(px + (ry + d) * FAST_PPITCH) + lane;
-                A[d] = row[0]; B[d] = row[1]; Cw[d] = row[2];
-            }
-            // Two pixels per operation: E holds pixels j = 0 and 2 as 16-bit halves, O pixels 1 and 3.
-            // Every opposite ring pair must have a member brighter than v+t (resp. darker than v-t):
-            // min over pairs of the pair maximum > v+t, max over pairs of the pair minimum < v-t.
-            fast_u2 mn_of_mx[2], mx_of_mn[2];
+        for (int j = 0; j < 4; j++)
+            if (x0 + j >= 3 && x0 + j < w - 3) inside |= 1u << j;
+        inside |= inside << 4;
+        unsigned A[rows_per_wave + 6], B[rows_per_wave + 6], Cw[rows_per_wave + 6];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-#pragma unroll
-                for (int o = 0; o < 2; o++) {
-                    const fast_u2 r0 = ring_pair(A[3 + ring_dy(k)], B[3 + ring_dy(k)], Cw[3 + ring_dy(k)], ring_dx(k), o);
-                    const fast_u2 r1 = ring_pair(A[3 + ring_dy(k + 8)], B[3 + ring_dy(k + 8)], Cw[3 + ring_dy(k + 8)], ring_dx(k + 8), o);
-                    const fast_u2 mx = __builtin_elementwise_max(r0, r1), mn = __builtin_elementwise_min(r0, r1);
-                    mn_of_mx[o] = k == 0 ? mx : __builtin_elementwise_min(mn_of_mx[o], mx);
-                    mx_of_mn[o] = k == 0 ? mn : __builtin_elementwise_max(mx_of_mn[o], mn);
-                }
-            }
-            const fast_u2 T = fast_u2{(unsigned short)t, (unsigned short)t};
-#pragma unroll
-            for (int o = 0; o < 2; o++) {
-                const fast_u2 v = ring_pair(A[3], B[3], Cw[3], 0, o);
-                // bright: mn_of_mx > v + t; dark: mx_of_mn + t < v (saturating differences are non-zero exactly then)
-                const fast_u2 hit = __builtin_elementwise_sub_sat(mn_of_mx[o], v + T) | __builtin_elementwise_sub_sat(v, mx_of_mn[o] + T);
-                if (hit.x != 0) cand |= 1u << o;
-                if (hit.y != 0) cand |= 4u << o;
-            }
-            // only pixels with a full ring inside the image are tested (3 <= x < w - 3)
-            unsigned inside = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (x0 + j >= 3 && x0 + j < w - 3) inside |= 1u << j;
-            cand &= inside;
+        for (int d = 0; d < rows_per_wave + 6; d++) {
+            const fl_u32* row = reinterpret_cast<const fl_u32*>(px + (ry0 + d) * FAST_PPITCH) + lane;
+            A[d] = row[0]; B[d] = row[1]; Cw[d] = row[2];
         }
-        // append the candidates of these 256 pixels to the wavefront's list: (row in share << 8) | score column
-        // (the list's order is irrelevant: every entry is scored on its own)
-        if (__ballot(cand != 0u) != 0ull) {
-            const unsigned mine = (unsigned)__popc(cand);
+#pragma unroll
+        for (int q = 0; q < rows_per_wave; q++) {
+            const int y = y0 - 1 + ry0 + q;
+            unsigned cb = 0, cd = 0;
+            if (y >= 3 && y < h - 3 && !(diag & 1)) fast_pair_test(A + q, B + q, Cw + q, t, cb, cd);      // wave-uniform condition
+            const unsigned byte = (cb | (cd << 4)) & inside;
+            if (q < 4) cand_lo |= byte << (8 * q);
+            else cand_hi |= byte << (8 * (q - 4));
+        }
+    }
+    // Candidates are listed row by row: (dark << 15) | (row << 8) | score column (the order inside the list is
+    // irrelevant: every entry is scored on its own).  The list is scored (phase 2) when the next row might not fit any
+    // more, and after the last row: sparse candidates of all 8 rows share one pass of the scorer.
+    int n = 0;
+    const int rr_end = __ballot((cand_lo | cand_hi) != 0u) != 0ull ? rows_per_wave : -1;      // no candidate in the 8 rows: nothing to list
+    for (int rr = 0; rr <= rr_end; rr++) {
+        if (n > 0 && (rr == rows_per_wave || n + 2 * FAST_CW > FAST_LIST)) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (diag & 2) n = 0;
+            // ---- phase 2: exact score of the listed candidates, two per lane (one in each 16-bit half of the arithmetic)
+            for (int i = lane; 2 * i < n; i += 64) {
+                const int e1 = mylist[2 * i], e2 = mylist[min(2 * i + 1, n - 1)];      // an odd count: the last entry twice
+                const int c1 = e1 & 255, ry1 = wid * rows_per_wave + ((e1 >> 8) & 0x7f);
+                const int c2 = e2 & 255, ry2 = wid * rows_per_wave + ((e2 >> 8) & 0x7f);
+                const unsigned xm = ((e1 & 0x8000) ? 0xFFu : 0u) | ((e2 & 0x8000) ? 0xFF0000u : 0u);
+                const fast_s2 a = fast_arc_scores2(px + (ry1 + 3) * FAST_PPITCH + 4 + c1, px + (ry2 + 3) * FAST_PPITCH + 4 + c2, FAST_PPITCH, xm);
+                // a pixel cannot hold a bright and a dark arc of 9 at once: of its (at most two) entries one at most stores
+                if (a.x > t) sc[ry1 * FAST_CW + c1] = (unsigned char)(nonmax ? a.x - 1 : a.x);   // no NMS: score + 1 marks a corner
+                if (a.y > t) sc[ry2 * FAST_CW + c2] = (unsigned char)(nonmax ? a.y - 1 : a.y);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the list is reused by the next rows
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            n = 0;
+        }
+        if (rr == rows_per_wave) break;
+        const unsigned cbd = ((rr < 4 ? cand_lo : cand_hi) >> (8 * (rr & 3))) & 0xffu;
+        if (__ballot(cbd != 0u) != 0ull) {
+            const unsigned mine = (unsigned)__popc(cbd);
             const unsigned incl = wave_scan_incl(mine);
             int pos = n + (int)(incl - mine);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if ((cand >> j) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
+            for (int j = 0; j < 4; j++) {
+                if ((cbd >> j) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
+                if ((cbd >> (4 + j)) & 1u) mylist[pos++] = (unsigned short)(0x8000u | (rr << 8) | (4 * lane + j));
+            }
             n += __builtin_amdgcn_readlane((int)incl, 63);
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef FAST_DIAG_SKIP_P2
-    n = 0;
-#endif
-    // ---- phase 2: exact score of the listed candidates, one lane each
-    for (int i = lane; i < n; i += 64) {
-        const int e = mylist[i];
-        const int c = e & 255, ry = wid * rows_per_wave + (e >> 8);
-        int ad, ab;
-        fast_arc_scores(px + (ry + 3) * FAST_PPITCH + 4 + c, FAST_PPITCH, ad, ab);
-        const int a = max(ad, ab);
-        if (a > t) sc[ry * FAST_CW + c] = (unsigned char)(nonmax ? a - 1 : a);   // no NMS: score + 1 marks a corner
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the list is reused by the next rows
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __syncthreads();
 
@@ -276,11 +308,7 @@ __global__ __launch_bounds__(FAST_WG) void fast_tile_kernel(
         if (y >= h) break;                                       // wave-uniform
         const int seg = y * ntx + tx;
         int total = 0;
-#ifdef FAST_DIAG_SKIP_P3
-        if (y < -h) {
-#else
-        if (y >= 3 && y < h - 3) {
-#endif
+        if (y >= 3 && y < h - 3 && !(diag & 4)) {
             const fl_u8* row = sc + (ro + 1) * FAST_CW;          // score row of image row y
             const unsigned c4 = (lane >= 1 && lane <= FAST_TW / 4) ? *reinterpret_cast<const fl_u32*>(row + 4 * lane) : 0u;
             if (__ballot(c4 != 0u) != 0ull) {
@@ -413,6 +441,11 @@ __global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx,
 
 }  // namespace
 
+static int fast_diag_bits() {
+    static const int bits = [] { const char* e = getenv("SLAM_HIP_FAST_DIAG"); return e ? (atoi(e) & 7) : 0; }();
+    return bits;
+}
+
 extern "C" size_t slam_hip_fast_scratch_bytes(int w, int h, int nframes, int cap_per_frame) {
     FastPlan p;
     if (w < 1 || h < 1 || nframes < 1 || cap_per_frame < 1) return 0;
@@ -441,7 +474,7 @@ extern "C" int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, in
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     // every word of the tables that is read is written by the kernel before it: nothing to clear
     hipLaunchKernelGGL(fast_tile_kernel, dim3(p.ntx, p.nty, nframes), dim3(FAST_WG), 0, ctx->stream,
-                       d_frames, w, h, (long long)pitch, (long long)frame_stride, threshold, nonmax ? 1 : 0,
+                       d_frames, w, h, (long long)pitch, (long long)frame_stride, threshold, (nonmax ? 1 : 0) | (fast_diag_bits() << 8),
                        p.ntx, (unsigned*)d_scratch);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(fast_scan_kernel, dim3(nframes), dim3(FAST_WG), 0, ctx->stream, h, p.ntx, (unsigned*)d_scratch, d_counts);
@@ -526,7 +559,13 @@ extern "C" int slam_hip_get_sorted_keypoints(slam_ctx* ctx, const uint8_t* im, i
     std::vector<slam_keypoint> kps(kmax ? kmax : 1);
     float f = *fast_threshold;
     size_t n = 0;
-    while (n < n_min_pts) {                                   // new_point.cpp:116-122
+    // new_point.cpp:116-122: while (out.size() < nMinPts) { FAST(im, out, fastThreshold, true); fastThreshold *= .5; }
+    // The first pass runs at the current threshold and usually ends the loop.  When it does not, ONE more pass at
+    // threshold 0 serves every later iteration: a corner's score does not depend on the threshold it was detected
+    // with, and a pixel survives non-max suppression at threshold t >= 1 exactly when it survives at threshold 0 and
+    // its score is at least t (a neighbour that is no corner at t scores below t, hence below the pixel), so the
+    // list of iteration t is the threshold-0 list, in its row-major order, without the scores below t.
+    {
         const int t = (int)f;                                 // FAST(im, out, fastThreshold, true): float -> int
         int32_t cnt = 0;
         rc = fast_detect_resident(ctx, (const uint8_t*)ctx->d_stage[0], w, h, dpitch, dstride, 1, t, 1,
@@ -534,7 +573,24 @@ extern "C" int slam_hip_get_sorted_keypoints(slam_ctx* ctx, const uint8_t* im, i
         if (rc != SLAM_HIP_OK) return rc;
         n = (size_t)cnt;
         f *= 0.5f;
-        if (t <= 0) break;   // the reference never leaves this loop on a corner-poor image; stop after t = 0
+        if (n < n_min_pts && t > 0) {       // the reference never leaves this loop on a corner-poor image; here it stops after t = 0
+            rc = fast_detect_resident(ctx, (const uint8_t*)ctx->d_stage[0], w, h, dpitch, dstride, 1, 0, 1,
+                                      kps.data(), (int)kps.size(), &cnt);
+            if (rc != SLAM_HIP_OK) return rc;
+            const size_t n0 = (size_t)cnt;
+            for (;;) {
+                const int ti = (int)f;
+                n = 0;
+                for (size_t i = 0; i < n0; i++) n += kps[i].response >= (float)ti;
+                f *= 0.5f;
+                if (n >= n_min_pts || ti <= 0) {
+                    size_t k = 0;
+                    for (size_t i = 0; i < n0; i++)
+                        if (kps[i].response >= (float)ti) kps[k++] = kps[i];
+                    break;
+                }
+            }
+        }
     }
     f *= 2.f;                                                 // new_point.cpp:123
     // new_point.cpp:124 sorts by response only with an unstable sort; ties are fixed as y, x ascending

@@ -490,6 +490,28 @@ def test_get_sorted_keypoints_matches_oracle(ctx, oracle):
     assert len(got) == 0
 
 
+def test_one_pass_at_threshold_zero_serves_every_threshold(ctx, oracle):
+    """The halving loop of getSortedKeyPoints (new_point.cpp:116-122) is served by one detector pass: the list of
+    threshold t is the threshold-0 list, in order, without the scores below t - checked against separate passes and
+    against the oracle, on a noisy texture and on one quantised so coarsely that equal scores sit side by side."""
+    rng = np.random.default_rng(91 + SOAK_SEED)
+    flat = (rng.integers(0, 6, (96, 128)) * 40).astype(np.uint8)
+    for im in (synth.frame(320, 240, 77 + SOAK_SEED), flat):
+        base, _, _ = api.fast(ctx, im, 0, True)
+        l0 = base[0]
+        assert np.array_equal(l0, oracle.fast(im, 0, True))
+        for t in (10, 5, 2, 1, 0):
+            got, _, _ = api.fast(ctx, im, t, True)
+            assert np.array_equal(got[0], l0[l0[:, 2] >= t])
+            assert np.array_equal(got[0], oracle.fast(im, t, True))
+    # and the loop itself: a first threshold far too high, halved down to where enough corners appear
+    for (nmin, f0) in [(100, 200.0), (2000, 37.0), (10 ** 6, 9.0)]:
+        im = synth.frame(320, 240, 78 + SOAK_SEED)
+        ref, fref = oracle.get_sorted_keypoints(im, nmin, f0)
+        got, fgot = api.get_sorted_keypoints(ctx, im, nmin, f0)
+        assert fgot == fref and np.array_equal(got, ref)
+
+
 # ---- committed golden vectors (tests/golden/make_golden.py) -------------------------------------
 def test_golden_vectors_on_gpu(ctx):
     import sys
