@@ -42,11 +42,31 @@ bool fast_plan(int w, int h, FastPlan& p) {
     return true;
 }
 
-// Per-frame scratch (4-byte words): rowcnt[h * ntx], rowoff[h * ntx], then the key table: one segment of
-// FAST_TW 16-bit keys ((column in tile << 8) | stored score) per (row, tile), rows padded to whole words.
-__host__ __device__ inline size_t fast_tab_words(int h, int ntx) { return ((size_t)h * ntx + 3) / 4 * 4; }
+// Per-frame scratch (4-byte words): rowcnt and rowoff, 32 words per tile each (one per tile row, tile-major, so a tile
+// writes and reads whole 128-byte lines), then the key table: FAST_TW * FAST_TH slots per tile of 16-bit keys
+// ((column in tile << 8) | stored score); a tile's keys fill its slots from the first, in row-major order, so the bytes
+// written and read back are the keys themselves rather than one part-filled line per row.
+__host__ __device__ inline size_t fast_tab_words(int h, int ntx) { return (size_t)((h + FAST_TH - 1) / FAST_TH) * ntx * 32; }
 __host__ __device__ inline size_t fast_frame_words(int h, int ntx) {
-    return 2 * fast_tab_words(h, ntx) + (size_t)h * ntx * (FAST_TW / 2);
+    return 2 * fast_tab_words(h, ntx) + (size_t)((h + FAST_TH - 1) / FAST_TH) * ntx * (FAST_TW * FAST_TH / 2);
+}
+
+// With 8 frames or more in a launch, all tiles of a frame run on one XCD (workgroups are dealt to the 8 XCDs round-robin
+// by linear index), so the halo rows and the 128-byte lines that neighbouring tiles share are fetched from HBM once and
+// found in that XCD's L2 afterwards.  The grid is then one-dimensional: 8 * ceil(nframes / 8) * tiles_per_frame.
+struct FastTile { int tx, ty, frame; };
+__device__ __forceinline__ FastTile fast_tile_of_block(int ntx, int nty, int nframes) {
+    FastTile f;
+    if (gridDim.y == 1 && gridDim.z == 1 && nframes >= 8) {
+        const unsigned b = blockIdx.x, per = (unsigned)(ntx * nty), g = b >> 3;
+        const unsigned round = g / per, tile = g - round * per;
+        f.frame = (int)(round * 8 + (b & 7));
+        f.ty = (int)(tile / (unsigned)ntx);
+        f.tx = (int)(tile - (unsigned)f.ty * ntx);
+    } else {
+        f.tx = blockIdx.x; f.ty = blockIdx.y; f.frame = blockIdx.z;
+    }
+    return f;
 }
 
 typedef __attribute__((address_space(3))) unsigned char fl_u8;
@@ -156,7 +176,7 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
 
 __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
     const uint8_t* __restrict__ frames, int w, int h, long long pitch, long long frame_stride,
-    int threshold, int nonmax, int ntx, unsigned* __restrict__ scratch) {
+    int threshold, int nonmax, int ntx, int nty, int nframes, unsigned* __restrict__ scratch) {
     __shared__ __attribute__((aligned(16))) unsigned char px_s[FAST_PR * FAST_PPITCH];    // pixels
     __shared__ __attribute__((aligned(16))) unsigned char sc_s[FAST_SR * FAST_CW];        // stored scores
     __shared__ unsigned short lists_s[4 * FAST_LIST];
@@ -164,7 +184,9 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
     fl_u8* sc = (fl_u8*)sc_s;
     fl_u16* lists = (fl_u16*)lists_s;
 
-    const int tx = blockIdx.x, ty = blockIdx.y, frame = blockIdx.z;
+    const FastTile bt = fast_tile_of_block(ntx, nty, nframes);
+    const int tx = bt.tx, ty = bt.ty, frame = bt.frame;
+    if (frame >= nframes) return;                               // the last round of 8 frames may be short
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint8_t* im = frames + (long long)frame * frame_stride;
     const int cx0 = tx * FAST_TW, y0 = ty * FAST_TH;            // first output column / row of the tile
@@ -298,15 +320,19 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
     }
     __syncthreads();
 
-    // ---- phase 3: non-max suppression; every (row, tile) segment is compacted in column order
-    const int nseg = h * ntx;
-    unsigned* rowcnt = fs;
-    unsigned short* keys = reinterpret_cast<unsigned short*>(fs + 2 * fast_tab_words(h, ntx));
-    const int r_lo = (FAST_TH * wid) >> 2, r_hi = (FAST_TH * (wid + 1)) >> 2;   // this wavefront's output rows
+    // ---- phase 3: non-max suppression.  Pass A finds the kept pixels of the wavefront's rows (4 bits per lane and row,
+    // 8 rows in one register) and the rows' counts; the wavefronts' totals give each its first slot in the tile's key
+    // area; pass B writes the keys there in row-major order.
+    unsigned* rowcnt = fs + (size_t)(ty * ntx + tx) * 32;
+    fl_u32* wtot = (fl_u32*)lists;                               // the candidate lists are done with
+    fl_u32* rowtot = wtot + 4;
+    unsigned short* tkeys = reinterpret_cast<unsigned short*>(fs + 2 * fast_tab_words(h, ntx)) +
+                            (size_t)(ty * ntx + tx) * (FAST_TW * FAST_TH);
+    const int r_lo = (FAST_TH * wid) >> 2, r_hi = (FAST_TH * (wid + 1)) >> 2;   // this wavefront's output rows (7 or 8)
+    unsigned keepbits = 0;
+    int wave_total = 0;
     for (int ro = r_lo; ro < r_hi; ro++) {
         const int y = y0 + ro;
-        if (y >= h) break;                                       // wave-uniform
-        const int seg = y * ntx + tx;
         int total = 0;
         if (y >= 3 && y < h - 3 && !(diag & 4)) {
             const fl_u8* row = sc + (ro + 1) * FAST_CW;          // score row of image row y
@@ -343,31 +369,46 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
                             if ((c4 >> (8 * j)) & 0xffu) keep |= 1u << j;
                     }
                 }
-                // column order inside the row = lane-major, then j
-                int before = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const unsigned long long bal = __ballot((keep >> j) & 1u);
-                    before += __popcll(bal & ((1ull << lane) - 1ull));
-                    total += __popcll(bal);
-                }
-                if (keep) {
-                    unsigned short* kseg = keys + (size_t)seg * FAST_TW;
-                    int pos = before;
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if ((keep >> j) & 1u) {
-                            const unsigned s = (c4 >> (8 * j)) & 0xffu;
-                            kseg[pos++] = (unsigned short)(((unsigned)(4 * lane - 4 + j) << 8) | (nonmax ? s : s - 1u));
-                        }
-                }
+                keepbits |= keep << (4 * (ro - r_lo));
+                total = __popcll(__ballot(keep & 1u)) + __popcll(__ballot(keep & 2u)) + __popcll(__ballot(keep & 4u)) + __popcll(__ballot(keep & 8u));
             }
         }
-        if (lane == 0 && seg < nseg) rowcnt[seg] = (unsigned)total;
+        wave_total += total;
+        if (lane == 0) rowtot[ro] = (unsigned)total;
+    }
+    if (lane == 0) wtot[wid] = (unsigned)wave_total;
+    __syncthreads();
+    if (wid == 0 && lane < FAST_TH) rowcnt[lane] = rowtot[lane];
+    if (wave_total == 0) return;                                 // wave-uniform; no barrier follows
+    int slot = 0;
+    for (int k = 0; k < wid; k++) slot += (int)wtot[k];
+    for (int ro = r_lo; ro < r_hi; ro++) {
+        const unsigned keep = (keepbits >> (4 * (ro - r_lo))) & 15u;
+        if (__ballot(keep != 0u) == 0ull) continue;
+        // column order inside the row = lane-major, then j
+        int before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long bal = __ballot((keep >> j) & 1u);
+            before += __popcll(bal & ((1ull << lane) - 1ull));
+            total += __popcll(bal);
+        }
+        if (keep) {
+            const unsigned c4 = *reinterpret_cast<const fl_u32*>(sc + (ro + 1) * FAST_CW + 4 * lane);
+            int pos = slot + before;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((keep >> j) & 1u) {
+                    const unsigned sv = (c4 >> (8 * j)) & 0xffu;
+                    tkeys[pos++] = (unsigned short)(((unsigned)(4 * lane - 4 + j) << 8) | (nonmax ? sv : sv - 1u));
+                }
+        }
+        slot += total;
     }
 }
 
-// One workgroup per frame: exclusive prefix sums of the (row, tile) counts in row-major order.
+// One workgroup per frame: exclusive prefix sums of the (row, tile) counts in row-major order (row y of tile column tx
+// is word (y / FAST_TH * ntx + tx) * 32 + y % FAST_TH of the tables).
 __global__ __launch_bounds__(FAST_WG) void fast_scan_kernel(int h, int ntx, unsigned* __restrict__ scratch, int* __restrict__ counts) {
     __shared__ unsigned part[4];
     __shared__ unsigned carry;
@@ -381,8 +422,13 @@ __global__ __launch_bounds__(FAST_WG) void fast_scan_kernel(int h, int ntx, unsi
     for (int base = 0; base < n; base += FAST_WG * 4) {
         const int i0 = base + tid * 4;
         unsigned c[4];
+        int at[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) c[q] = (i0 + q < n) ? rowcnt[i0 + q] : 0u;
+        for (int q = 0; q < 4; q++) {
+            const int i = i0 + q, y = i / ntx, tx = i - y * ntx, ty = y / FAST_TH;
+            at[q] = (ty * ntx + tx) * 32 + (y - ty * FAST_TH);
+            c[q] = i < n ? rowcnt[at[q]] : 0u;
+        }
         const unsigned mine = c[0] + c[1] + c[2] + c[3];
         const unsigned incl = wave_scan_incl(mine);
         if ((tid & 63) == 63) part[tid >> 6] = incl;
@@ -391,7 +437,7 @@ __global__ __launch_bounds__(FAST_WG) void fast_scan_kernel(int h, int ntx, unsi
         for (int k = 0; k < (tid >> 6); k++) off += part[k];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if (i0 + q < n) rowoff[i0 + q] = off;
+            if (i0 + q < n) rowoff[at[q]] = off;
             off += c[q];
         }
         __syncthreads();
@@ -404,10 +450,12 @@ __global__ __launch_bounds__(FAST_WG) void fast_scan_kernel(int h, int ntx, unsi
 // One wavefront per tile: lane r looks up row r's segment; the tile's keys are then numbered across its
 // rows and dealt to the lanes 64 at a time (a binary search over the rows' running totals finds the
 // segment of key number i), so the lanes stay busy however few keys a single row holds.
-__global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx, int cap, const unsigned* __restrict__ scratch,
-                                                          slam_keypoint* __restrict__ out) {
+__global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx, int nty, int nframes, int cap,
+                                                          const unsigned* __restrict__ scratch, slam_keypoint* __restrict__ out) {
     __shared__ int start_s[32], off_s[32];
-    const int tx = blockIdx.x, ty = blockIdx.y, frame = blockIdx.z;
+    const FastTile bt = fast_tile_of_block(ntx, nty, nframes);
+    const int tx = bt.tx, ty = bt.ty, frame = bt.frame;
+    if (frame >= nframes) return;
     const int lane = threadIdx.x;
     const unsigned* fs = scratch + (size_t)frame * fast_frame_words(h, ntx);
     const unsigned* rowcnt = fs;
@@ -416,7 +464,7 @@ __global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx,
     slam_keypoint* o = out + (size_t)frame * cap;
     const int y_l = ty * FAST_TH + lane;
     int n_l = 0, off_l = 0;
-    if (lane < FAST_TH && y_l < h) { n_l = (int)rowcnt[y_l * ntx + tx]; off_l = (int)rowoff[y_l * ntx + tx]; }
+    if (lane < FAST_TH && y_l < h) { n_l = (int)rowcnt[(ty * ntx + tx) * 32 + lane]; off_l = (int)rowoff[(ty * ntx + tx) * 32 + lane]; }
     const int incl = (int)wave_scan_incl((unsigned)n_l);
     const int total = __builtin_amdgcn_readlane(incl, 63);
     if (total == 0) return;
@@ -427,11 +475,10 @@ __global__ __launch_bounds__(64) void fast_scatter_kernel(int w, int h, int ntx,
 #pragma unroll
         for (int step = 16; step >= 1; step >>= 1)
             if (start_s[r + step] <= i) r += step;
-        const int k = i - start_s[r];
-        const long long dst = (long long)(unsigned)off_s[r] + k;
+        const long long dst = (long long)(unsigned)off_s[r] + (i - start_s[r]);
         if (dst < cap) {
             const int y = ty * FAST_TH + r;
-            const unsigned key = keys[(size_t)(y * ntx + tx) * FAST_TW + k];
+            const unsigned key = keys[(size_t)(ty * ntx + tx) * (FAST_TW * FAST_TH) + i];
             slam_keypoint kp;
             kp.x = (float)(tx * FAST_TW + (int)(key >> 8)); kp.y = (float)y; kp.response = (float)(key & 0xffu);
             o[dst] = kp;
@@ -473,13 +520,16 @@ extern "C" int slam_hip_fast_detect_d(slam_ctx* ctx, const uint8_t* d_frames, in
     threshold = std::min(std::max(threshold, 0), 255);          // cv::FAST clamps the threshold
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     // every word of the tables that is read is written by the kernel before it: nothing to clear
-    hipLaunchKernelGGL(fast_tile_kernel, dim3(p.ntx, p.nty, nframes), dim3(FAST_WG), 0, ctx->stream,
+    // 8 frames or more: one-dimensional grid, a frame per XCD (fast_tile_of_block)
+    const long long flat = (long long)((nframes + 7) / 8 * 8) * p.ntx * p.nty;
+    const dim3 grid = (nframes >= 8 && flat < (1ll << 24)) ? dim3((unsigned)flat) : dim3(p.ntx, p.nty, nframes);
+    hipLaunchKernelGGL(fast_tile_kernel, grid, dim3(FAST_WG), 0, ctx->stream,
                        d_frames, w, h, (long long)pitch, (long long)frame_stride, threshold, (nonmax ? 1 : 0) | (fast_diag_bits() << 8),
-                       p.ntx, (unsigned*)d_scratch);
+                       p.ntx, p.nty, nframes, (unsigned*)d_scratch);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(fast_scan_kernel, dim3(nframes), dim3(FAST_WG), 0, ctx->stream, h, p.ntx, (unsigned*)d_scratch, d_counts);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(fast_scatter_kernel, dim3(p.ntx, p.nty, nframes), dim3(64), 0, ctx->stream, w, h, p.ntx,
+    hipLaunchKernelGGL(fast_scatter_kernel, grid, dim3(64), 0, ctx->stream, w, h, p.ntx, p.nty, nframes,
                        cap_per_frame, (const unsigned*)d_scratch, d_out);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
