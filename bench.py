@@ -396,12 +396,15 @@ def c1_leg(api, capi, ctx, stream, dev, args, traffic):
         for f in range(4, nfr):                                    # all frames are the same image: results repeat with period 4
             assert np.array_equal(same[f], same[f & 3])
         parity = "every (feature, mask mode) pair equals the oracle bit for bit; all %d jobs repeat those" % len(jobs)
+    deferred = C.c_int32(0)
+    capi.check(ctx.handle, L.slam_hip_debug_walk_deferred(ctx.handle, C.byref(deferred)))
     ms = timed(stream, go, max(5, args.steps))
     positions = float(cells[k_idx, mode].sum())
     alg = float(byts[k_idx, mode].sum())
-    out = search_report("match_kernel@%d" % len(jobs), "match_kernel", ms, positions, alg, positions * 2 * ts * ts, traffic,
+    out = search_report("match_lean_kernel@%d+match_kernel@%d" % (len(jobs), min(len(jobs), 4096)), "match_lean_kernel+match_kernel", ms, positions, alg, positions * 2 * ts * ts, traffic,
                         {"workload": "C1: %dx%d, %d features/frame, %dx%d templates, %dx%d windows, stride 1, four mask modes mixed; %d frames"
-                                     % (w, h, nfeat, ts, ts, win, win, nfr), "jobs": len(jobs), "parity": parity})
+                                     % (w, h, nfeat, ts, ts, win, win, nfr), "jobs": len(jobs),
+                         "jobs_left_to_general_kernel": deferred.value, "parity": parity})
     pyr.close()
     return out
 

@@ -480,6 +480,13 @@ def match_lines_batch(ctx, pyr, jobs):
             for r in res[:n]]
 
 
+def debug_walk_deferred(ctx):
+    """Jobs the last lean kernel launch of this context left to the general kernel (walks or single searches)."""
+    n = C.c_int32(0)
+    check(ctx.handle, lib().slam_hip_debug_walk_deferred(ctx.handle, C.byref(n)))
+    return n.value
+
+
 def debug_score_formulas(ctx, cc, si, sp):
     cc = np.ascontiguousarray(cc, np.uint64)
     si = np.ascontiguousarray(si, np.uint64)

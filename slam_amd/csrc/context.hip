@@ -49,6 +49,10 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     c->no_lean = (nl && nl[0] == '1') ? 1 : 0;
     const char* wk = getenv("SLAM_HIP_WALK_LDS_KB");
     if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) c->lean_lds_bytes = atoi(wk) * 1024;
+    const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");
+    if (sk && atoi(sk) >= 4 && atoi(sk) <= 64) c->lean_match_lds_bytes = atoi(sk) * 1024;
+    const char* sm = getenv("SLAM_HIP_SEARCH_LEAN_MIN");
+    if (sm && atoi(sm) >= 1) c->lean_match_min_jobs = atoi(sm);
     const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");
     if (lk && atoi(lk) >= 4 && atoi(lk) <= 63) c->match_lds_bytes = c->line_lds_bytes = atoi(lk) * 1024;
     const int rc = slam_track_scratch_init(c);             // this device's copy of the no-alloc walk queue

@@ -173,16 +173,11 @@ __device__ __forceinline__ long long lane_i64(long long v, int i) {
 }
 __device__ __forceinline__ double lane_f64(double v, int i) { return __longlong_as_double(lane_i64(__double_as_longlong(v), i)); }
 
-__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
-                                                        int njobs, const uint8_t* __restrict__ blob,
-                                                        unsigned long long blob_bytes, float* scores,
-                                                        unsigned long long scores_len,
-                                                        slam_match_result* __restrict__ out, int force_direct, int lds_total) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    lds_u8* lds = (lds_u8*)dyn_lds;
-    const LdsPlan plan = make_lds_plan(lds_total);
-    const int j = blockIdx.x;
-    if (j >= njobs) return;
+// SLAM::matchFeatureInArea (matching.cpp:9-228) for job j, general form.
+__device__ __forceinline__ void match_job(const slam_pyr_dev& pyr, const slam_match_job* __restrict__ jobs, int j,
+                                          const uint8_t* __restrict__ blob, unsigned long long blob_bytes, float* scores,
+                                          unsigned long long scores_len, slam_match_result* __restrict__ out, int force_direct,
+                                          lds_u8* lds, const LdsPlan& plan) {
     const slam_match_job job = jobs[j];
     bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.level >= 0 && job.level < pyr.nlev &&
               job.pw >= 1 && job.ph >= 1 && job.pw <= 32767 && job.ph <= 32767 && job.stride >= 1 && job.stride <= (1 << 20) &&
@@ -225,6 +220,88 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
     STAMP_DECL;
     const CoreOut o = match_core(g, t, sc, lds, plan, force_direct != 0, true, 0.0 STAMP_PASS);
     if (threadIdx.x == 0) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
+}
+
+#define SLAM_DEFER_LIST 16
+
+// General single-search kernel.  queue == nullptr: workgroup b takes job b.  Otherwise the workgroups share out the jobs
+// the lean kernel queued (a later launch on the same stream: its counter and list are complete and visible).
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_bytes, float* scores,
+                                                        unsigned long long scores_len,
+                                                        slam_match_result* __restrict__ out, int force_direct, int lds_total,
+                                                        const int* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const LdsPlan plan = make_lds_plan(lds_total);
+    if (!queue) {
+        const int j = blockIdx.x;
+        if (j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
+        return;
+    }
+    const int count = min(queue[0], njobs);
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const int j = queue[SLAM_DEFER_LIST + q];
+        __syncthreads();                                   // the previous job's last readers of the dynamic LDS
+        if (j >= 0 && j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
+    }
+}
+
+// Lean single-search kernel: one matchFeatureInArea call whose candidate patches all lie inside the image, without a
+// score map, small enough for lean_level (match_lean.h).  With a patch mask the cells of the stride lattice inside
+// the area mask are scored by the F32 formula (matching.cpp:64-73); without one every cell is scored by
+// matchTemplate's normalisation whatever the stride (matching.cpp:151-153), and an area mask removes cells only
+// when it is exact (matching.cpp:157-163).  Any other job is appended to the queue for match_kernel; nothing is
+// written to `out` for it here.
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_lean_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob,
+                                                        unsigned long long blob_bytes, const float* scores,
+                                                        slam_match_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_match_job job = jobs[j];
+    STAMP_DECL;
+    bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.level >= 0 && job.level < pyr.nlev &&
+              job.pw >= 1 && job.ph >= 1 && job.pw <= 255 && job.ph <= 255 && job.stride >= 1 && job.stride <= 1024 &&
+              job.aw >= 1 && job.ah >= 1 && job.aw <= 255 && job.ah <= 255 &&
+              job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28) &&
+              !(scores && job.score_off >= 0);
+    const long long pbytes = (long long)job.pw * job.ph;
+    ok = ok && span_ok(job.patch_off, pbytes, blob_bytes);
+    if (job.pmask_off != -1) ok = ok && span_ok(job.pmask_off, pbytes, blob_bytes);
+    if (job.amask_off != -1) ok = ok && span_ok(job.amask_off, (long long)job.aw * job.ah, blob_bytes);
+    LeanOut o;
+    o.ok = false;
+    if (ok) {
+        int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
+#pragma unroll
+        for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++)
+            if (l == job.level) { lw = pyr.lev[l].w; lh = pyr.lev[l].h; lp = pyr.lev[l].pitch; ls = pyr.lev[l].frame_stride; ld = pyr.lev[l].data; }
+        LeanLevel L;
+        L.im = ld + (long long)job.frame * ls;
+        L.ipitch = (unsigned)lp; L.w = lw; L.h = lh;
+        L.tw = job.pw; L.th = job.ph; L.srcw = job.pw; L.srch = job.ph;
+        L.resized = false; L.scx = 1.0; L.scy = 1.0;
+        L.patch = blob + job.patch_off; L.limit = blob + blob_bytes;
+        L.mask = job.pmask_off != -1 ? blob + job.pmask_off : nullptr;
+        L.mt = job.pmask_off == -1;
+        L.x0 = job.ax - job.pw / 2; L.y0 = job.ay - job.ph / 2;                       // matching.cpp:38-39
+        L.aw = job.aw; L.ah = job.ah;
+        L.step = L.mt ? 1 : job.stride;
+        L.amask = (job.amask_off != -1 && (!L.mt || job.use_exact_area_mask != 0)) ? blob + job.amask_off : nullptr;
+        // every candidate patch inside the image (no crop, no border cells: matching.cpp:19-25,44-49), image rows that
+        // can be fetched as aligned dwords
+        ok = L.x0 >= 0 && L.y0 >= 0 && L.x0 + L.aw + L.tw - 1 <= L.w && L.y0 + L.ah + L.th - 1 <= L.h && lp <= 0x7fffffffLL &&
+             ((reinterpret_cast<unsigned long long>(L.im) | (unsigned long long)lp) & 3ull) == 0;
+        if (ok) o = lean_level<true>(L, lds, lds_total, true, 0.0 STAMP_PASS);
+    }
+    if (threadIdx.x == 0) {
+        if (o.ok) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
+        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
+    }
 }
 
 // per-level constants of a point walk, one LDS entry per pyramid level
@@ -353,8 +430,6 @@ __device__ __forceinline__ void track_job(const slam_pyr_dev& pyr, const slam_tr
 }
 
 // Queue of jobs the lean kernel left to the general one: word 0 counts them, the job indices start at word 16.
-#define SLAM_DEFER_LIST 16
-
 // General walk kernel.  queue == nullptr: workgroup b walks job b.  Otherwise the workgroups share out the jobs the
 // lean kernel queued (a later launch on the same stream: its counter and list are complete and visible).
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
@@ -401,6 +476,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
     LeanLevel L;
     L.patch = blob + job.proj_off; L.mask = blob + job.mask_off; L.limit = blob + blob_bytes;
     L.srcw = job.projw; L.srch = job.projh;
+    L.mt = false;                               // walks carry a patch mask: the F32 formula (matching.cpp:70-72)
     const double stop_below = __dmul_rn(0.67, (double)job.threshold);           // feature.cpp:151
     float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
     float response = 0.f, sdx = 0.f, sdy = 0.f;
@@ -477,7 +553,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
             LEAN_REJECT(12 + 1000 * i); return false;
         }
         // feature.cpp:151-152: the level that ends the walk also reports the sub-pixel fit
-        const LeanOut o = lean_level(L, lds, lds_total, i == 0, stop_below STAMP_PASS);
+        const LeanOut o = lean_level<false>(L, lds, lds_total, i == 0, stop_below STAMP_PASS);
         if (!o.ok) return false;
         levels_run++;
         response = o.response; sdx = o.dx; sdy = o.dy;
@@ -665,9 +741,27 @@ extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
+    // Small batches (single reference calls among them) go straight to the general kernel: the lean kernel's queue
+    // costs a clear and a second launch, which only a batch repays.
+    if (ctx->force_direct || ctx->no_lean || njobs < ctx->lean_match_min_jobs) {
+        hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
+                           pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
+                           (unsigned long long)scores_len, d_out, ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
+        SLAM_HIP_CHECK(ctx, hipGetLastError());
+        return SLAM_HIP_OK;
+    }
+    rc = slam_queue_reserve(ctx, njobs);
+    if (rc != SLAM_HIP_OK) return rc;
+    int* queue = ctx->d_queue;
+    SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(match_lean_kernel, dim3(njobs), dim3(SLAM_WG), ctx->lean_match_lds_bytes, ctx->stream,
+                       pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, (const float*)d_scores, d_out,
+                       ctx->lean_match_lds_bytes, queue);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());
+    const int grid = njobs < 4096 ? njobs : 4096;
+    hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
-                       (unsigned long long)scores_len, d_out, ctx->force_direct, ctx->match_lds_bytes);
+                       (unsigned long long)scores_len, d_out, 0, ctx->match_lds_bytes, (const int*)queue);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }

@@ -1,11 +1,11 @@
-// Lean search of one pyramid level for the point walk (SLAM::Feature::track, feature.cpp:124-152): the common case
-// in which every candidate patch of the window lies inside the image, the template is small and the whole score
-// map fits one job's LDS at once.  Same integer sums, same formulas and the same argmax rule as the general core
-// (match_fast.h); what differs is the data layout, chosen so that the inner loop is nearly nothing but v_dot4:
+// Lean search of one window: a pyramid level of the point walk (SLAM::Feature::track, feature.cpp:124-152) or a single
+// SLAM::matchFeatureInArea call (matching.cpp:9-228), in the common case in which every candidate patch of the window
+// lies inside the image and the template is small.  Same integer sums, same formulas and the same argmax rule as the
+// general core (match_fast.h); what differs is the data layout, chosen so that the inner loop is nearly nothing but v_dot4:
 //
-//   tile   : the image rows under all cells, one 16-byte entry per dword position p of a row holding the four byte
-//            windows that start at bytes 4p, 4p+1, 4p+2, 4p+3 - the shifts are paid once per tile, not per
-//            (cell, template group), and a strip of 4 adjacent cells gets its 4 windows with one ds_read_b128
+//   tile   : the image rows under all cells, one 8-byte entry per dword position p of a row holding the byte windows
+//            that start at bytes 4p (W0) and 4p+3 (W3); the two windows in between are one v_perm_b32 each, so a strip
+//            of 4 adjacent cells gets its 4 windows from one ds_read_b64
 //   lists  : the template's 4-pixel groups as a list of {P0 = patch*mask, tile offset} entries; groups whose mask is
 //            all zero are dropped, groups that keep all four pixels come first (their window needs no masking before
 //            its energy is summed), the others follow with their mask in a parallel array.  Both parts are padded to
@@ -13,7 +13,7 @@
 //   acc    : {CC, SI} per cell, u32, LDS atomics
 //
 // A lane owns a unit (a strip of 4 adjacent cells at stride 1, one cell on a coarser lattice) and one of S slices of
-// the entry lists.  Anything this path does not cover is left to the general kernel: the caller defers the job.
+// the entry lists.  Anything this path does not cover is left to the general kernel: the caller queues the job.
 #pragma once
 
 #include "match_fast.h"
@@ -69,10 +69,11 @@ struct LeanLevel {           // wave-uniform description of one level's search
     int step;                // lattice step: cells (i*step, j*step) are visited (matching.cpp:64-66 with xl0 = yl0 = 0)
     const uint8_t* amask;    // area mask (pitch aw) or nullptr: cells whose byte is 0 are not visited (matching.cpp:66)
     const uint8_t* patch;    // full-resolution template and mask, pitch srcw
-    const uint8_t* mask;
+    const uint8_t* mask;     //   nullptr: no patch mask, every template pixel counts
     const uint8_t* limit;    // end of the buffer they live in
     int srcw, srch;
     bool resized;            // template resized to (tw, th) on the fly (feature.cpp:130-131)
+    bool mt;                 // scores by cv::matchTemplate's normalisation (matching.cpp:151-153: the modes without a patch mask)
     double scx, scy;
 };
 
@@ -130,9 +131,10 @@ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int ste
 // the rows (unit = strip * ah + row)
 __device__ __forceinline__ int lean_strip_cell(int c, int y, int ah) { return ((c >> 2) * ah + y) * 4 + (c & 3); }
 
-// the F32 score (matching.cpp:70-72) of a cell from its sums; the caller has checked that the cell is visited
-__device__ __forceinline__ float lean_score(const lds_u32* acc, int ai, float p2f) {
-    return score_f32_n(acc[2 * ai], acc[2 * ai + 1], p2f);
+// the score of a cell from its sums - the F32 formula (matching.cpp:70-72) or matchTemplate's (matching.cpp:152); the
+// caller has checked that the cell is visited
+__device__ __forceinline__ float lean_score(const lds_u32* acc, int ai, const Norms& nm, bool mt) {
+    return mt ? score_mt_n(acc[2 * ai], acc[2 * ai + 1], nm.tn) : score_f32_n(acc[2 * ai], acc[2 * ai + 1], nm.p2f);
 }
 
 // One entry of the lists for the NC cells of a unit: cc += <window, P0>, si += <window & M, window & M>.  A tile entry
@@ -223,27 +225,54 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
     }
 }
 
-// One level.  `refine`: also report the sub-pixel offset of the peak (the level that ends a walk does).
-// Returns ok = false when the level is not covered here (nothing has been written anywhere).
+// One search.  SEARCH = false: a level of a point walk - a patch mask is present, scores by the F32 formula, and the caller
+// has checked (lean_need) that the whole window fits the LDS at once.  SEARCH = true: a single matchFeatureInArea call -
+// the patch mask may be absent, the formula is L.mt's, and a window whose sums do not fit the LDS at once is searched
+// in blocks of rows (the lists are built once; tile, sums and scores per block; the first maximum in row-major order
+// carries over from block to block).  `refine_*`: also report the sub-pixel offset of the peak (the level that ends a
+// walk does; single searches always do).  Returns ok = false when the search is not covered here (nothing has been
+// written anywhere).
+template <bool SEARCH>
 __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, int lds_total, bool refine_always, double refine_below STAMP_ARG) {
     LeanOut out;
     out.ok = false; out.x = 0; out.y = 0; out.response = 0.f; out.dx = 0.f; out.dy = 0.f;
     const int lane = lane_here();
+    const bool mt = SEARCH && L.mt;
+    const bool has_mask = !SEARCH || L.mask != nullptr;
     const int G = (L.tw + 3) >> 2, NG = L.th * G;
     const int o = L.x0 & 3;
     const bool strips = L.step == 1;
     const int nx = strips ? L.aw : small_div_u(L.aw + L.step - 1, L.step), ny = strips ? L.ah : small_div_u(L.ah + L.step - 1, L.step);
     const int cols = (o + L.aw + 3) >> 2;                  // dword columns that hold a cell's first pixel
     const int tp = (cols + G - 1) | 1;                     // window positions per tile row, odd: see lean_accumulate
-    const int trows = L.ah + L.th - 1;
-    const int nunits = strips ? cols * L.ah : nx * ny;
-    const int nacc = strips ? nunits * 4 : nunits;
+    const int rows_all = strips ? L.ah : ny;               // rows of units: cell rows at stride 1, lattice rows otherwise
+    const int rstep = strips ? 1 : L.step;                 // image rows from one unit row to the next
+    const int upr = strips ? cols : nx;                    // units per row
+    const int cpu = strips ? 4 : 1;                        // cells per unit
     const int cap = NG + LEAN_MAX_S + 8;                   // room for the padding entries and for reads a few entries ahead
-    const int acc_bytes = (nacc * 8 + 15) & ~15;
     const int list_bytes = cap * 8, marr_bytes = (cap * 4 + 15) & ~15;
-    if (lean_need(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized) > lds_total) { LEAN_REJECT(100); return out; }
+    int bh = rows_all, nblk = 1;                           // unit rows per block, blocks
+    if (!SEARCH) {
+        if (lean_need(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized) > lds_total) { LEAN_REJECT(100); return out; }
+    } else {
+        // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
+        if (L.tw > 256 || L.th > 256 || L.tw * L.th > 66051 || tp > 64) { LEAN_REJECT(101); return out; }
+        const int raw_bytes = NG * 8 + (L.resized ? (G * 4 + L.th) * 8 : 0);
+        const int fixed = list_bytes + marr_bytes + 32;    // + rounding of the two regions around them
+        const int per_row = upr * cpu * 8 + rstep * tp * 8;
+        const int room = lds_total - fixed - (L.th - rstep) * tp * 8;
+        int r = room > 0 ? small_div_u(room, per_row) : 0;
+        const int room2 = lds_total - fixed - raw_bytes;   // the template is staged where the tile goes afterwards
+        const int r2 = room2 > 0 ? small_div_u(room2, upr * cpu * 8) : 0;
+        r = min(min(r, r2), rows_all);
+        if (r < min(3, rows_all) || lds_total > (1 << 19)) { LEAN_REJECT(102); return out; }      // the fit needs three rows at once
+        nblk = small_div_u(rows_all + r - 1, r);
+        bh = small_div_u(rows_all + nblk - 1, nblk);
+    }
     // tile rows are fetched as aligned dwords: a needed byte must not sit in a partial last dword of the image row
     if (L.x0 + L.aw + L.tw - 1 > (L.w & ~3)) { LEAN_REJECT(2); return out; }
+    // room for the three rows around the peak too, when blocks are lower than that (they fit: r above is at least 3)
+    const int acc_bytes = (max(bh, min(3, rows_all)) * upr * cpu * 8 + 15) & ~15;
     lds_u32* acc = reinterpret_cast<lds_u32*>(lds);
     lds_u64* list = reinterpret_cast<lds_u64*>(lds + acc_bytes);
     lds_u32* marr = reinterpret_cast<lds_u32*>(lds + acc_bytes + list_bytes);
@@ -253,7 +282,6 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
 
     STAMP(50);
     __syncthreads();                                       // the previous level's readers of this LDS are done
-    for (int i = lane; i < nacc * 2; i += SLAM_WG) acc[i] = 0;
 
     // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
     unsigned sp_part = 0;
@@ -267,7 +295,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G;
                 const long long so = (long long)u * L.srcw + gq * 4;
                 const unsigned P = load4(L.patch + so, L.limit);
-                const unsigned Mraw = load4(L.mask + so, L.limit);
+                const unsigned Mraw = has_mask ? load4(L.mask + so, L.limit) : 0x01010101u;
                 const int nb = min(4, L.tw - gq * 4);
                 const unsigned keep = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
                 const unsigned nz = (((Mraw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | Mraw) & 0x80808080u;   // per byte: non-zero -> 0x80
@@ -293,34 +321,24 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         lds_u8* rb = reinterpret_cast<lds_u8*>(raw);
         const float rw = __builtin_amdgcn_rcpf((float)wpx);
         const int n = L.th * wpx;
-        constexpr int NB = 1;
-        for (int i0 = 0; i0 < n; i0 += NB * SLAM_WG) {
-            ResizeSrc spx[NB], smx[NB];
-            unsigned long long txq[NB], tyq[NB];
-            int eo[NB]; bool pad[NB], live[NB];
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                const int ii = i0 + q * SLAM_WG + lane;
-                live[q] = ii < n;
-                const int i = min(ii, n - 1);
-                const int u = (int)(((float)i + 0.5f) * rw), v = i - u * wpx;
-                txq[q] = taps[min(v, L.tw - 1)]; tyq[q] = taps[wpx + u];
-                pad[q] = v >= L.tw;
-                eo[q] = (u * G + (v >> 2)) * 8 + (v & 3);
-                smx[q] = resize_fetch(L.mask, L.srcw, L.srch, (int)(unsigned)txq[q], (int)(unsigned)tyq[q]);
-                spx[q] = resize_fetch(L.patch, L.srcw, L.srch, (int)(unsigned)txq[q], (int)(unsigned)tyq[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < NB; q++) {
-                const int a0 = (short)(txq[q] >> 32), a1 = (short)(txq[q] >> 48), b0 = (short)(tyq[q] >> 32), b1 = (short)(tyq[q] >> 48);
-                unsigned m = (unsigned)(resize_blend(smx[q], a0, a1, b0, b1, true) != 0);
-                unsigned p = (unsigned)resize_blend(spx[q], a0, a1, b0, b1, false) * m;
-                if (pad[q]) { p = 0; m = 0; }
-                if (live[q]) {
-                    sp_part += p * p;
-                    rb[eo[q]] = (unsigned char)p;
-                    rb[eo[q] + 4] = m ? 0xFF : 0x00;
-                }
+        for (int i0 = 0; i0 < n; i0 += SLAM_WG) {
+            const int ii = i0 + lane;
+            const bool live = ii < n;
+            const int i = min(ii, n - 1);
+            const int u = (int)(((float)i + 0.5f) * rw), v = i - u * wpx;
+            const unsigned long long txq = taps[min(v, L.tw - 1)], tyq = taps[wpx + u];
+            const bool pad = v >= L.tw;
+            const int eo = (u * G + (v >> 2)) * 8 + (v & 3);
+            const ResizeSrc spx = resize_fetch(L.patch, L.srcw, L.srch, (int)(unsigned)txq, (int)(unsigned)tyq);
+            const ResizeSrc smx = has_mask ? resize_fetch(L.mask, L.srcw, L.srch, (int)(unsigned)txq, (int)(unsigned)tyq) : spx;
+            const int a0 = (short)(txq >> 32), a1 = (short)(txq >> 48), b0 = (short)(tyq >> 32), b1 = (short)(tyq >> 48);
+            unsigned m = has_mask ? (unsigned)(resize_blend(smx, a0, a1, b0, b1, true) != 0) : 1u;
+            unsigned p = (unsigned)resize_blend(spx, a0, a1, b0, b1, false) * m;
+            if (pad) { p = 0; m = 0; }
+            if (live) {
+                sp_part += p * p;
+                rb[eo] = (unsigned char)p;
+                rb[eo + 4] = m ? 0xFF : 0x00;
             }
         }
         __syncthreads();
@@ -336,7 +354,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     STAMP(51);
 
     // ---- entry lists --------------------------------------------------------------------------------------------
-    const LeanSlices lsl = lean_pick_slices(nunits, nA, nB, strips);
+    const LeanSlices lsl = lean_pick_slices(bh * upr, nA, nB, strips);
     const int S = lsl.S, na = lsl.na, nA1 = na * S;           // all-kept entries per slice; the rest of them joins the masked part
     const int nb = lsl.nb, nB1 = nb * S;
     __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
@@ -358,117 +376,159 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         }
         for (int p = nA + nB + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p] = 0u; }   // padding: adds nothing
     }
-    __syncthreads();                                        // raw and taps are dead: the tile goes over them
     STAMP(52);
 
-    // ---- image tile: byte windows W0 and W3 of every dword position ----------------------------------------------------
-    {
-        const int lg = 32 - __builtin_clz((unsigned)tp);   // 2^lg > tp lanes per tile row
-        const int c = lane & ((1 << lg) - 1), lr = lane >> lg, rpp = SLAM_WG >> lg;
-        if (c < tp) {
-            // Bytes past the image row's last whole dword are only ever read for padding cells and padding template
-            // columns (whose sums are dropped or masked to zero), and rows past the tile by nobody: such loads are
-            // clamped onto valid dwords instead of being predicated.
-            const unsigned lastd = (unsigned)(L.w >> 2) - 1u;
-            const unsigned dcol = (unsigned)((L.x0 - o) >> 2) + (unsigned)c;
-            const unsigned g0 = min(dcol, lastd) * 4u, g1 = min(dcol + 1u, lastd) * 4u;
-            const uint8_t* src = L.im + (unsigned long long)L.y0 * L.ipitch;
-            const int nit = (trows + rpp - 1) >> (6 - lg);   // wave-uniform
-            for (int it = 0; it < nit; it += 4) {
-                unsigned d0[4], d1[4], ro[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    ro[q] = (unsigned)min(lr + (it + q) * rpp, trows - 1);
-                    d0[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g0);
-                    d1[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g1);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned w3 = __builtin_amdgcn_alignbyte(d1[q], d0[q], 3);
-                    *reinterpret_cast<lds_u64*>(tile + (ro[q] * (unsigned)tp + (unsigned)c) * 8u) = ((unsigned long long)w3 << 32) | d0[q];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    STAMP(53);
-
-    // ---- sums -------------------------------------------------------------------------------------------------------
-    if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, L.ah, tp, o, 1);
-    else lean_accumulate<1>(tile, list, marr, acc, nunits, S, na, nb, nA1, nx, tp, o, L.step);
-    __syncthreads();
-    STAMP(54);
-
-    // ---- scores and argmax (cv::minMaxLoc: first maximum in row-major order, NaN never wins) ---------------------------
-    const int ncell = nx * ny;
+    // ---- blocks of rows: tile, sums, scores; after the last one the argmax and, for the fit, the rows around it ----
     const float rnx = __builtin_amdgcn_rcpf((float)nx);
     Best b = {-FLT_MAX, INT_MAX};
-    constexpr int NQ = 8;
-    if (ncell <= SLAM_WG) {                                // one cell per lane
-        if (lane < ncell) {
-            const int cy = (int)(((float)lane + 0.5f) * rnx), cx = lane - cy * nx;
-            const int x = cx * L.step, y = cy * L.step;
-            if (!(L.amask && L.amask[y * L.aw + x] == 0))
-                best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, y, L.ah) : lane, nm.p2f), (y << 16) | x);
+    int r0 = 0, rows_b = rows_all;                          // the block whose sums the accumulators hold
+    int lx = 0, ly = 0;
+    float bv = 0.f;
+    for (int blk = 0; blk <= nblk; blk++) {
+        if (blk == nblk) {
+            // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The
+            // wave's maximum first, then the smallest cell index among the lanes that hold it (cv::minMaxLoc: first
+            // maximum in row-major order, NaN never wins).
+            const unsigned bkey = wave_max_u32(b.idx != INT_MAX ? __float_as_uint(b.v) + 1u : 0u);
+            const int bidx = (int)wave_min_u32((b.idx != INT_MAX && __float_as_uint(b.v) + 1u == bkey) ? (unsigned)b.idx : 0xFFFFFFFFu);
+            bv = __uint_as_float(bkey - 1u);
+            STAMP(55);
+            // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is
+            // a -1 of the untouched score map or there is none at all: the general kernel knows those cases.
+            if (bkey == 0u) { LEAN_REJECT(3); return out; }
+            lx = bidx & 0xffff; ly = bidx >> 16;
+            out.ok = true;
+            out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
+            out.response = bv;
+            if (!(refine_always || (double)bv < refine_below)) return out;
+            if (!strips) return out;                       // off the lattice the four neighbours are unvisited: no fit
+            if (nblk == 1) break;                          // the sums of the only block are still in place
+            r0 = max(ly - 1, 0); rows_b = min(ly + 1, L.ah - 1) - r0 + 1;
+        } else {
+            r0 = blk * bh; rows_b = min(bh, rows_all - r0);
         }
-    } else if (ncell <= NQ * SLAM_WG && nm.tn > 0.0) {
-        // Single-precision estimates first (relative error below 1e-6): only cells within 1e-5 of the largest estimate
-        // can hold the maximum or tie with it, and only those are scored with the exact formula.  -FLT_MAX marks cells
-        // that are not visited or whose exact score is NaN (an all-zero window).
-        const float rn = __builtin_amdgcn_rcpf(nm.p2f);
-        float est[NQ], m = -FLT_MAX;
-        int ai[NQ], key[NQ];
+        const int nunits = rows_b * upr;
+        __syncthreads();                                    // lists complete; the previous block's readers of tile and sums done
+        for (int i = lane; i < nunits * cpu * 2; i += SLAM_WG) acc[i] = 0;
+        {   // image tile: byte windows W0 and W3 of every dword position
+            const int trows = (rows_b - 1) * rstep + L.th;
+            const int lg = 32 - __builtin_clz((unsigned)tp);   // 2^lg > tp lanes per tile row
+            const int c = lane & ((1 << lg) - 1), lr = lane >> lg, rpp = SLAM_WG >> lg;
+            if (c < tp) {
+                // Bytes past the image row's last whole dword are only ever read for padding cells and padding template
+                // columns (whose sums are dropped or masked to zero), and rows past the tile by nobody: such loads are
+                // clamped onto valid dwords instead of being predicated.
+                const unsigned lastd = (unsigned)(L.w >> 2) - 1u;
+                const unsigned dcol = (unsigned)((L.x0 - o) >> 2) + (unsigned)c;
+                const unsigned g0 = min(dcol, lastd) * 4u, g1 = min(dcol + 1u, lastd) * 4u;
+                const uint8_t* src = L.im + (unsigned long long)(L.y0 + r0 * rstep) * L.ipitch;
+                const int nit = (trows + rpp - 1) >> (6 - lg);   // wave-uniform
+                for (int it = 0; it < nit; it += 4) {
+                    unsigned d0[4], d1[4], ro[4];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            est[q] = -FLT_MAX; ai[q] = 0; key[q] = 0;
-            if (q * SLAM_WG < ncell) {
-                const int i = q * SLAM_WG + lane;
-                const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
-                const int x = cx * L.step, y = cy * L.step;
-                if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0)) {
-                    ai[q] = strips ? lean_strip_cell(o + x, y, L.ah) : i;
-                    key[q] = (y << 16) | x;
-                    const unsigned CC = acc[2 * ai[q]], SI = acc[2 * ai[q] + 1];
-                    if (SI != 0u) est[q] = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+                    for (int q = 0; q < 4; q++) {
+                        ro[q] = (unsigned)min(lr + (it + q) * rpp, trows - 1);
+                        d0[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g0);
+                        d1[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g1);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned w3 = __builtin_amdgcn_alignbyte(d1[q], d0[q], 3);
+                        *reinterpret_cast<lds_u64*>(tile + (ro[q] * (unsigned)tp + (unsigned)c) * 8u) = ((unsigned long long)w3 << 32) | d0[q];
+                    }
                 }
-                m = fmaxf(m, est[q]);
             }
         }
-        // estimates are >= 0 or the marker, so their bit patterns order like the values once the marker is mapped to 0
-        m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
-        const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+        __syncthreads();
+        STAMP(53);
+        if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, rows_b, tp, o, 1);
+        else lean_accumulate<1>(tile, list, marr, acc, nunits, S, na, nb, nA1, nx, tp, o, L.step);
+        __syncthreads();
+        STAMP(54);
+        if (blk == nblk) break;                            // the rows around the peak: no scores, the fit reads the sums
+
+        // ---- scores of the block's cells ---------------------------------------------------------------------------
+        const int ncell = nx * rows_b;
+        constexpr int NQ = 8;
+        if (ncell <= SLAM_WG) {                            // one cell per lane
+            if (lane < ncell) {
+                const int cy = (int)(((float)lane + 0.5f) * rnx), cx = lane - cy * nx;
+                const int x = cx * L.step, y = (r0 + cy) * L.step;
+                if (!(L.amask && L.amask[y * L.aw + x] == 0))
+                    best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b) : lane, nm, mt), (y << 16) | x);
+            }
+        } else if (ncell <= NQ * SLAM_WG && nm.tn > 0.0) {
+            // Single-precision estimates first (relative error below 1e-6): only cells within 1e-5 of the largest estimate
+            // can hold the maximum or tie with it, and only those are scored with the exact formula.  -FLT_MAX marks cells
+            // that are not visited or whose exact score is NaN (an all-zero window under the F32 formula).
+            const float rn = __builtin_amdgcn_rcpf(nm.p2f);
+            float est[NQ], m = -FLT_MAX;
+            int ai[NQ], key[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; q++)
-            if (q * SLAM_WG < ncell && est[q] != -FLT_MAX && est[q] >= keep_from) best_update(b, lean_score(acc, ai[q], nm.p2f), key[q]);
-    } else {
-        for (int i = lane; i < ncell; i += SLAM_WG) {
-            const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
-            const int x = cx * L.step, y = cy * L.step;
-            if (L.amask && L.amask[y * L.aw + x] == 0) continue;
-            best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, y, L.ah) : i, nm.p2f), (y << 16) | x);
+            for (int q = 0; q < NQ; q++) {
+                est[q] = -FLT_MAX; ai[q] = 0; key[q] = 0;
+                if (q * SLAM_WG < ncell) {
+                    const int i = q * SLAM_WG + lane;
+                    const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+                    const int x = cx * L.step, y = (r0 + cy) * L.step;
+                    if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0)) {
+                        ai[q] = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                        key[q] = (y << 16) | x;
+                        const unsigned CC = acc[2 * ai[q]], SI = acc[2 * ai[q] + 1];
+                        if (SI != 0u) est[q] = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+                        else if (mt) est[q] = 0.f;           // matchTemplate scores an all-zero window 0, the F32 formula NaN
+                    }
+                    m = fmaxf(m, est[q]);
+                }
+            }
+            // estimates are >= 0 or the marker, so their bit patterns order like the values once the marker is mapped to 0
+            m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
+            const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if (q * SLAM_WG < ncell && est[q] != -FLT_MAX && est[q] >= keep_from) best_update(b, lean_score(acc, ai[q], nm, mt), key[q]);
+        } else if (nm.tn > 0.0) {
+            // the same with more cells than registers: the estimates are formed twice, once for their maximum and once
+            // to pick the cells that get the exact formula
+            const float rn = __builtin_amdgcn_rcpf(nm.p2f);
+            float m = -FLT_MAX;
+            for (int i = lane; i < ncell; i += SLAM_WG) {
+                const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+                const int x = cx * L.step, y = (r0 + cy) * L.step;
+                if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+                const int ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
+                if (SI != 0u) m = fmaxf(m, (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn);
+                else if (mt) m = fmaxf(m, 0.f);
+            }
+            m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
+            const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+            for (int i = lane; i < ncell; i += SLAM_WG) {
+                const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+                const int x = cx * L.step, y = (r0 + cy) * L.step;
+                if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+                const int ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
+                float est = -FLT_MAX;
+                if (SI != 0u) est = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+                else if (mt) est = 0.f;
+                if (est != -FLT_MAX && est >= keep_from) best_update(b, lean_score(acc, ai, nm, mt), (y << 16) | x);
+            }
+        } else {
+            for (int i = lane; i < ncell; i += SLAM_WG) {
+                const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+                const int x = cx * L.step, y = (r0 + cy) * L.step;
+                if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+                best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b) : i, nm, mt), (y << 16) | x);
+            }
         }
     }
-    // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The wave's
-    // maximum first, then the smallest cell index among the lanes that hold it.
-    const unsigned bkey = wave_max_u32(b.idx != INT_MAX ? __float_as_uint(b.v) + 1u : 0u);
-    const int bidx = (int)wave_min_u32((b.idx != INT_MAX && __float_as_uint(b.v) + 1u == bkey) ? (unsigned)b.idx : 0xFFFFFFFFu);
-    const float bv = __uint_as_float(bkey - 1u);
-    STAMP(55);
-    // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is a
-    // -1 of the untouched score map or there is none at all: the general kernel knows those cases.
-    if (bkey == 0u) { LEAN_REJECT(3); return out; }
-    const int lx = bidx & 0xffff, ly = bidx >> 16;
-    out.ok = true;
-    out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
-    out.response = bv;
-    if (!(refine_always || (double)bv < refine_below)) return out;
-    if (!strips) return out;                               // off the lattice the four neighbours are unvisited: no fit
-    // sub-pixel fit through the four neighbours of the peak: lanes 0..3 score one each
+    // sub-pixel fit through the four neighbours of the peak: lanes 0..3 score one each from the sums of rows r0 .. r0 + rows_b - 1
     const int n = lane & 3;
     const int qx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0), qy = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
     const bool in = qx >= 0 && qy >= 0 && qx < L.aw && qy < L.ah;
     float v = -1.f;
-    if (in && !(L.amask && L.amask[qy * L.aw + qx] == 0)) v = lean_score(acc, lean_strip_cell(o + qx, qy, L.ah), nm.p2f);
+    if (in && !(L.amask && L.amask[qy * L.aw + qx] == 0)) v = lean_score(acc, lean_strip_cell(o + qx, qy - r0, rows_b), nm, mt);
     const float sl = __shfl(v, 0, 64), sr = __shfl(v, 1, 64), su = __shfl(v, 2, 64), sd = __shfl(v, 3, 64);
     const bool okl = __shfl((int)in, 0, 64) != 0, okr = __shfl((int)in, 1, 64) != 0;
     const bool oku = __shfl((int)in, 2, 64) != 0, okd = __shfl((int)in, 3, 64) != 0;

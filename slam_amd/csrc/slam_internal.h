@@ -23,7 +23,9 @@ struct slam_ctx {
     int match_lds_bytes = 9 * 1024;    // LDS per search job: 16 jobs share a CU's 160 KB, as many as its registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
     int force_direct = 0;   // SLAM_HIP_FORCE_DIRECT=1: search by direct evaluation (cross-check of the tiled core)
     int lean_lds_bytes = 8192;         // LDS per job of the lean walk kernel: 20 jobs per CU
-    int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: point walks skip the lean kernel (cross-check of it)
+    int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: walks and searches skip the lean kernels (cross-check of them)
+    int lean_match_lds_bytes = 10240;  // LDS per job of the lean single-search kernel (SLAM_HIP_SEARCH_LDS_KB)
+    int lean_match_min_jobs = 64;      // smaller batches of single searches take the general kernel alone (SLAM_HIP_SEARCH_LEAN_MIN)
     // queue of walk jobs the lean kernel leaves to the general one: a counter word, then the job indices
     int* d_queue = nullptr;
     size_t queue_jobs = 0;

@@ -187,6 +187,50 @@ def test_match_random_medium_all_modes(ctx, oracle, use_pm, use_am):
         _check_match(ctx, oracle, im, patch, pm, area, am, int(rng.integers(1, 5)), bool(rng.integers(0, 2)))
 
 
+def test_match_batches_take_the_lean_kernel_with_the_same_results(ctx, oracle):
+    """Batches of single searches (64 jobs and more go to the lean single-search kernel first, the jobs it does not
+    cover to the general one): random windows in all four mask modes, most of them interior, some over the image
+    border, exact and lax area masks, strides 1 to 4, planted patches, few grey levels (tied maxima), all-zero
+    windows; every job against the oracle."""
+    rng = np.random.default_rng(4100 + SOAK_SEED)
+    w, h = 200, 150
+    frames = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+    frames[1] = frames[1] >> 6 << 6
+    frames[0, 40:70, 50:90] = 0
+    pyr = api.ImagePyramid(ctx, frames, [1.0])
+    jobs = []
+    try:
+        for it in range(160):
+            f = int(rng.integers(0, 2))
+            pw, ph = int(rng.integers(1, 26)), int(rng.integers(1, 26))
+            aw, ah = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+            if it % 8 == 7:                                     # anywhere, the image border included
+                ax, ay = int(rng.integers(-aw - 2, w + 2)), int(rng.integers(-ah - 2, h + 2))
+            else:                                               # every candidate patch inside the image
+                ax = int(rng.integers(pw // 2, max(pw // 2 + 1, w - aw - pw + pw // 2 + 2)))
+                ay = int(rng.integers(ph // 2, max(ph // 2 + 1, h - ah - ph + ph // 2 + 2)))
+            patch = rng.integers(0, 256, (ph, pw), dtype=np.uint8)
+            if it % 3 == 0:
+                x = int(rng.integers(0, w - pw + 1)); y = int(rng.integers(0, h - ph + 1))
+                patch = frames[f, y:y + ph, x:x + pw].copy()
+            mode = it & 3
+            pm = (rng.random((ph, pw)) < 0.8).astype(np.uint8) if mode & 1 else None
+            am = (rng.random((ah, aw)) < 0.7).astype(np.uint8) if mode & 2 else None
+            jobs.append(dict(frame=f, level=0, patch=patch, patch_mask=pm, area=(ax, ay, aw, ah), area_mask=am,
+                             stride=int(rng.integers(1, 5)), exact=bool(rng.integers(0, 2))))
+        got = api.match_batch(ctx, pyr, jobs)
+        left = api.debug_walk_deferred(ctx)
+        assert 0 < left < len(jobs) // 2, left                 # the border jobs, and few others
+        for k, (j, g) in enumerate(zip(jobs, got)):
+            ref = oracle.match(frames[j["frame"]], j["patch"], j["patch_mask"], j["area"], j["area_mask"], j["stride"], j["exact"])
+            assert g["status"] == 0
+            assert (g["x"], g["y"]) == (ref["x"], ref["y"]), (k, j["area"], j["patch"].shape, j["stride"], j["exact"])
+            assert _same_float(g["response"], ref["response"]), k
+            assert _same_float(g["dx"], ref["dx"]) and _same_float(g["dy"], ref["dy"]), k
+    finally:
+        pyr.close()
+
+
 def test_match_edge_cases(ctx, oracle):
     rng = np.random.default_rng(5)
     im = rng.integers(0, 256, (30, 40), dtype=np.uint8)
