@@ -277,45 +277,65 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
             else cand_hi |= byte << (8 * (q - 4));
         }
     }
-    // Candidates are listed row by row: (dark << 15) | (row << 8) | score column (the order inside the list is
-    // irrelevant: every entry is scored on its own).  The list is scored (phase 2) when the next row might not fit any
-    // more, and after the last row: sparse candidates of all 8 rows share one pass of the scorer.
-    int n = 0;
-    const int rr_end = __ballot((cand_lo | cand_hi) != 0u) != 0ull ? rows_per_wave : -1;      // no candidate in the 8 rows: nothing to list
-    for (int rr = 0; rr <= rr_end; rr++) {
-        if (n > 0 && (rr == rows_per_wave || n + 2 * FAST_CW > FAST_LIST)) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (diag & 2) n = 0;
-            // ---- phase 2: exact score of the listed candidates, two per lane (one in each 16-bit half of the arithmetic)
-            for (int i = lane; 2 * i < n; i += 64) {
-                const int e1 = mylist[2 * i], e2 = mylist[min(2 * i + 1, n - 1)];      // an odd count: the last entry twice
-                const int c1 = e1 & 255, ry1 = wid * rows_per_wave + ((e1 >> 8) & 0x7f);
-                const int c2 = e2 & 255, ry2 = wid * rows_per_wave + ((e2 >> 8) & 0x7f);
-                const unsigned xm = ((e1 & 0x8000) ? 0xFFu : 0u) | ((e2 & 0x8000) ? 0xFF0000u : 0u);
-                const fast_s2 a = fast_arc_scores2(px + (ry1 + 3) * FAST_PPITCH + 4 + c1, px + (ry2 + 3) * FAST_PPITCH + 4 + c2, FAST_PPITCH, xm);
-                // a pixel cannot hold a bright and a dark arc of 9 at once: of its (at most two) entries one at most stores
-                if (a.x > t) sc[ry1 * FAST_CW + c1] = (unsigned char)(nonmax ? a.x - 1 : a.x);   // no NMS: score + 1 marks a corner
-                if (a.y > t) sc[ry2 * FAST_CW + c2] = (unsigned char)(nonmax ? a.y - 1 : a.y);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the list is reused by the next rows
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            n = 0;
+    // Candidates are listed as (dark << 15) | (row << 8) | score column (the order inside the list is irrelevant: every
+    // entry is scored on its own) and scored from the list (phase 2), two per lane.
+    auto score_list = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (diag & 2) n = 0;
+        // ---- phase 2: exact score of the listed candidates, two per lane (one in each 16-bit half of the arithmetic)
+        for (int i = lane; 2 * i < n; i += 64) {
+            const int e1 = mylist[2 * i], e2 = mylist[min(2 * i + 1, n - 1)];      // an odd count: the last entry twice
+            const int c1 = e1 & 255, ry1 = wid * rows_per_wave + ((e1 >> 8) & 0x7f);
+            const int c2 = e2 & 255, ry2 = wid * rows_per_wave + ((e2 >> 8) & 0x7f);
+            const unsigned xm = ((e1 & 0x8000) ? 0xFFu : 0u) | ((e2 & 0x8000) ? 0xFF0000u : 0u);
+            const fast_s2 a = fast_arc_scores2(px + (ry1 + 3) * FAST_PPITCH + 4 + c1, px + (ry2 + 3) * FAST_PPITCH + 4 + c2, FAST_PPITCH, xm);
+            // a pixel cannot hold a bright and a dark arc of 9 at once: of its (at most two) entries one at most stores
+            if (a.x > t) sc[ry1 * FAST_CW + c1] = (unsigned char)(nonmax ? a.x - 1 : a.x);   // no NMS: score + 1 marks a corner
+            if (a.y > t) sc[ry2 * FAST_CW + c2] = (unsigned char)(nonmax ? a.y - 1 : a.y);
         }
-        if (rr == rows_per_wave) break;
-        const unsigned cbd = ((rr < 4 ? cand_lo : cand_hi) >> (8 * (rr & 3))) & 0xffu;
-        if (__ballot(cbd != 0u) != 0ull) {
-            const unsigned mine = (unsigned)__popc(cbd);
-            const unsigned incl = wave_scan_incl(mine);
-            int pos = n + (int)(incl - mine);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the list is reused by the next rows
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const unsigned mine8 = (unsigned)(__popc(cand_lo) + __popc(cand_hi));
+    if (__ballot(mine8 != 0u) != 0ull) {                         // else: no candidate in the 8 rows, nothing to list
+        const unsigned incl8 = wave_scan_incl(mine8);
+        const int tot8 = __builtin_amdgcn_readlane((int)incl8, 63);
+        if (tot8 <= FAST_LIST) {
+            // the usual case: the candidates of all 8 rows fit the list - one scan, every lane writes its own entries
+            int pos = (int)(incl8 - mine8);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((cbd >> j) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
-                if ((cbd >> (4 + j)) & 1u) mylist[pos++] = (unsigned short)(0x8000u | (rr << 8) | (4 * lane + j));
+            for (int half = 0; half < 2; half++) {
+                unsigned bb = half ? cand_hi : cand_lo;
+                while (bb) {
+                    const int bi = __builtin_ctz(bb);
+                    bb &= bb - 1u;
+                    const int rr = half * 4 + (bi >> 3);
+                    mylist[pos++] = (unsigned short)((((unsigned)bi & 4u) << 13) | ((unsigned)rr << 8) | (unsigned)(4 * lane + (bi & 3)));
+                }
             }
-            n += __builtin_amdgcn_readlane((int)incl, 63);
+            score_list(tot8);
+        } else {
+            // dense rows: row by row, the list scored whenever another row (at most 2 * FAST_CW entries) might not fit
+            int n = 0;
+            for (int rr = 0; rr <= rows_per_wave; rr++) {
+                if (n > 0 && (rr == rows_per_wave || n + 2 * FAST_CW > FAST_LIST)) { score_list(n); n = 0; }
+                if (rr == rows_per_wave) break;
+                const unsigned cbd = ((rr < 4 ? cand_lo : cand_hi) >> (8 * (rr & 3))) & 0xffu;
+                if (__ballot(cbd != 0u) != 0ull) {
+                    const unsigned mine = (unsigned)__popc(cbd);
+                    const unsigned incl = wave_scan_incl(mine);
+                    int pos = n + (int)(incl - mine);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((cbd >> j) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
+                        if ((cbd >> (4 + j)) & 1u) mylist[pos++] = (unsigned short)(0x8000u | (rr << 8) | (4 * lane + j));
+                    }
+                    n += __builtin_amdgcn_readlane((int)incl, 63);
+                }
+            }
         }
     }
     __syncthreads();
