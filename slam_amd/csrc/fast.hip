@@ -102,30 +102,58 @@ __device__ __forceinline__ fast_u2 ring_pair(unsigned a, unsigned b, unsigned c,
     return __builtin_bit_cast(fast_u2, r);
 }
 
+__device__ __forceinline__ unsigned pk_sub_sat_u16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// Three-operand packed minimum / maximum exist on gfx950 for half floats only.  16-bit values below 0x400 are positive
+// subnormal half floats, which order like their bit patterns, so on such values these are integer min3 / max3.
+__device__ __forceinline__ unsigned pk_min3_h(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_max3_h(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // cv::FAST's cornerScore "A" value of two candidates at once, one per 16-bit half: max over the 16 arcs of 9 contiguous
 // ring pixels of the arc minimum of (ring - v) for a candidate of the bright polarity, of (v - ring) for the dark one.
 // A dark candidate is turned into a bright one by complementing its bytes (255 - x = x ^ 0xFF keeps differences):
-// xm holds 0xFF in the halves of dark candidates.  Window doubling: minima over 2, 4, 8 neighbours, then 9.
+// xm holds 0xFF in the halves of dark candidates.  The differences are kept with a bias of 256 (1..511: below 0x400, see
+// pk_min3_h): arc minima as min3 of min3 (9 = 3 x 3), their maximum by a max3 tree.
 __device__ __forceinline__ fast_s2 fast_arc_scores2(const fl_u8* p1, const fl_u8* p2, int pitch, unsigned xm) {
     const unsigned V = ((unsigned)p1[0] | ((unsigned)p2[0] << 16)) ^ xm;
-    fast_s2 e[16];
+    const unsigned W = 0x01000100u - V;                  // 256 - v per half, no borrow between the halves
+    unsigned e[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int o = ring_dy(k) * pitch + ring_dx(k);
-        const unsigned R = ((unsigned)p1[o] | ((unsigned)p2[o] << 16)) ^ xm;
-        e[k] = __builtin_bit_cast(fast_s2, R) - __builtin_bit_cast(fast_s2, V);
+        e[k] = (((unsigned)p1[o] | ((unsigned)p2[o] << 16)) ^ xm) + W;
     }
-    fast_s2 m2[16], m4[16], m8[16];
+    unsigned m3[16], m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 15]);
+    for (int k = 0; k < 16; k++) m3[k] = pk_min3_h(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+    for (int k = 0; k < 16; k++) m9[k] = pk_min3_h(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+    unsigned g[5];
 #pragma unroll
-    for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-    fast_s2 best = fast_s2{(short)-512, (short)-512};
-#pragma unroll
-    for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], e[(k + 8) & 15]));
-    return best;
+    for (int k = 0; k < 5; k++) g[k] = pk_max3_h(m9[3 * k], m9[3 * k + 1], m9[3 * k + 2]);
+    const unsigned best = pk_max_u16(pk_max3_h(g[0], g[1], g[2]), pk_max3_h(g[3], g[4], m9[15]));
+    return fast_s2{(short)((int)(best & 0xffffu) - 256), (short)((int)(best >> 16) - 256)};
 }
 
 // Opposite-pair test of a lane's 4 adjacent pixels (the window rows dy = -3..3 are A/B/Cw[0..6]: dwords at pixel bytes
@@ -159,6 +187,70 @@ __device__ __forceinline__ void fast_pair_test(const unsigned* A, const unsigned
     const unsigned pb = nb[0] | (nb[1] << 1), pd = nd[0] | (nd[1] << 1);
     candB = (pb & 3u) | ((pb >> 14) & 12u);
     candD = (pd & 3u) | ((pd >> 14) & 12u);
+}
+
+// The same test on precomputed shifted pairs: S[d][s + 3] holds bytes (4 + s, 6 + s) of window row d (s = -3..4) as
+// 16-bit halves, i.e. ring_pair(.., dx, o) with s = dx + o.  A window row's shifted pairs are shared by the pixel rows
+// and ring positions that meet on it (dy = -1, 0, +1 use the same four, dy = +-3 and dy = +-2 overlap in two), so the
+// 8 rows of a wavefront need about 100 byte picks instead of 272.  `q`: the pixel row, whose window rows are q .. q + 6.
+template <int Q>
+__device__ __forceinline__ void fast_pair_test_shared(const fast_u2 (&S)[FAST_SR / 4 + 6][8], int t, unsigned& flags) {
+    // Pixel values (0..255) in 16-bit halves are also positive subnormal half floats, which order like their bit
+    // patterns: the three-operand packed minimum / maximum of gfx950 (half-float only) halves the reduction trees.
+    unsigned mn_of_mx[2], mx_of_mn[2];
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        unsigned mx[8], mn[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const fast_u2 r0 = S[Q + 3 + ring_dy(k)][ring_dx(k) + o + 3];
+            const fast_u2 r1 = S[Q + 3 + ring_dy(k + 8)][ring_dx(k + 8) + o + 3];
+            mx[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(r0, r1));
+            mn[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(r0, r1));
+        }
+        unsigned a = pk_min3_h(mx[0], mx[1], mx[2]);
+        a = pk_min3_h(a, mx[3], mx[4]);
+        a = pk_min3_h(a, mx[5], mx[6]);
+        mn_of_mx[o] = pk_min_u16(a, mx[7]);
+        unsigned b = pk_max3_h(mn[0], mn[1], mn[2]);
+        b = pk_max3_h(b, mn[3], mn[4]);
+        b = pk_max3_h(b, mn[5], mn[6]);
+        mx_of_mn[o] = pk_max_u16(b, mn[7]);
+    }
+    // Flags of the lane's four pixels in one register: bright pixel j at bit (j & 1) + 16 * (j >> 1), dark two bits
+    // higher.  Saturating differences are non-zero exactly when the comparison holds; min(.., 1) makes them flags.
+    // (Written as instructions: left to itself the compiler turns each flag into a compare and a select.)
+    const unsigned T2 = (unsigned)t * 0x10001u, ONE = 0x10001u;     // no carry between the halves: pixel + t < 2^16
+    flags = 0;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        const unsigned v = __builtin_bit_cast(unsigned, S[Q + 3][o + 3]);
+        const unsigned nb = pk_min_u16(pk_sub_sat_u16(mn_of_mx[o], v + T2), ONE);
+        const unsigned nd = pk_min_u16(pk_sub_sat_u16(v, mx_of_mn[o] + T2), ONE);
+        flags |= (nb << o) | (nd << (2 + o));
+    }
+}
+
+template <int Q>
+__device__ __forceinline__ void fast_rows_shared(fast_u2 (&S)[FAST_SR / 4 + 6][8], const fl_u8* px, int ry0, int lane, int y_first, int h,
+                                                 int t, bool skip, unsigned inside, unsigned& cand_lo, unsigned& cand_hi) {
+    if constexpr (Q < FAST_SR / 4) {
+        // window rows 0..6 before the first pixel row, then one new row per pixel row
+#pragma unroll
+        for (int d = (Q == 0 ? 0 : Q + 6); d <= Q + 6; d++) {
+            const fl_u32* row = reinterpret_cast<const fl_u32*>(px + (ry0 + d) * FAST_PPITCH) + lane;
+            const unsigned a = row[0], b = row[1], c = row[2];
+#pragma unroll
+            for (int sft = -3; sft <= 4; sft++) S[d][sft + 3] = ring_pair(a, b, c, sft, 0);
+        }
+        const int y = y_first + Q;
+        unsigned flags = 0;
+        if (y >= 3 && y < h - 3 && !skip) fast_pair_test_shared<Q>(S, t, flags);      // wave-uniform condition
+        // four rows per register: row Q's flags sit 4 * (Q & 3) bits up, in bits 0..15 and 16..31 alike
+        if (Q < 4) cand_lo |= (flags & inside) << (4 * (Q & 3));
+        else cand_hi |= (flags & inside) << (4 * (Q & 3));
+        fast_rows_shared<Q + 1>(S, px, ry0, lane, y_first, h, t, skip, inside, cand_lo, cand_hi);
+    }
 }
 
 // Inclusive prefix sum over the 64 lanes with DPP moves: four row_shr steps inside each row of 16
@@ -250,32 +342,18 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
     constexpr int rows_per_wave = FAST_SR / 4;
     fl_u16* mylist = lists + wid * FAST_LIST;
     // Phase 1 proper: the pair test of the wavefront's 8 score rows.  The 14 window rows they span are read once (8
-    // score rows share them); every lane keeps one byte per row: bits 0..3 = its pixels that are bright candidates,
-    // bits 4..7 = dark candidates.
-    unsigned cand_lo = 0, cand_hi = 0;                           // rows 0..3 and 4..7, one byte each
+    // score rows share them); every lane keeps 8 flags per row (fast_pair_test_shared: pixel j bright at bit
+    // (j & 1) + 16 * (j >> 1), dark two bits higher), four rows to a register, row q shifted up by 4 * (q & 3).
+    unsigned cand_lo = 0, cand_hi = 0;                           // rows 0..3 and 4..7
     {
         const int ry0 = wid * rows_per_wave;
         const int x0 = cx0 - 4 + 4 * lane;                       // image column of the first of the lane's 4 pixels
         unsigned inside = 0;                                     // only pixels with a full ring inside the image are tested
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (x0 + j >= 3 && x0 + j < w - 3) inside |= 1u << j;
-        inside |= inside << 4;
-        unsigned A[rows_per_wave + 6], B[rows_per_wave + 6], Cw[rows_per_wave + 6];
-#pragma unroll
-        for (int d = 0; d < rows_per_wave + 6; d++) {
-            const fl_u32* row = reinterpret_cast<const fl_u32*>(px + (ry0 + d) * FAST_PPITCH) + lane;
-            A[d] = row[0]; B[d] = row[1]; Cw[d] = row[2];
-        }
-#pragma unroll
-        for (int q = 0; q < rows_per_wave; q++) {
-            const int y = y0 - 1 + ry0 + q;
-            unsigned cb = 0, cd = 0;
-            if (y >= 3 && y < h - 3 && !(diag & 1)) fast_pair_test(A + q, B + q, Cw + q, t, cb, cd);      // wave-uniform condition
-            const unsigned byte = (cb | (cd << 4)) & inside;
-            if (q < 4) cand_lo |= byte << (8 * q);
-            else cand_hi |= byte << (8 * (q - 4));
-        }
+            if (x0 + j >= 3 && x0 + j < w - 3) inside |= 5u << ((j & 1) + 16 * (j >> 1));     // both polarities
+        fast_u2 S[rows_per_wave + 6][8];
+        fast_rows_shared<0>(S, px, ry0, lane, y0 - 1 + ry0, h, t, (diag & 1) != 0, inside, cand_lo, cand_hi);
     }
     // Candidates are listed as (dark << 15) | (row << 8) | score column (the order inside the list is irrelevant: every
     // entry is scored on its own) and scored from the list (phase 2), two per lane.
@@ -312,8 +390,8 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
                 while (bb) {
                     const int bi = __builtin_ctz(bb);
                     bb &= bb - 1u;
-                    const int rr = half * 4 + (bi >> 3);
-                    mylist[pos++] = (unsigned short)((((unsigned)bi & 4u) << 13) | ((unsigned)rr << 8) | (unsigned)(4 * lane + (bi & 3)));
+                    const int rr = half * 4 + ((bi & 15) >> 2), j = (bi & 1) + 2 * (bi >> 4);
+                    mylist[pos++] = (unsigned short)((((unsigned)bi & 2u) << 14) | ((unsigned)rr << 8) | (unsigned)(4 * lane + j));
                 }
             }
             score_list(tot8);
@@ -323,15 +401,16 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
             for (int rr = 0; rr <= rows_per_wave; rr++) {
                 if (n > 0 && (rr == rows_per_wave || n + 2 * FAST_CW > FAST_LIST)) { score_list(n); n = 0; }
                 if (rr == rows_per_wave) break;
-                const unsigned cbd = ((rr < 4 ? cand_lo : cand_hi) >> (8 * (rr & 3))) & 0xffu;
+                const unsigned cbd = ((rr < 4 ? cand_lo : cand_hi) >> (4 * (rr & 3))) & 0x000F000Fu;
                 if (__ballot(cbd != 0u) != 0ull) {
                     const unsigned mine = (unsigned)__popc(cbd);
                     const unsigned incl = wave_scan_incl(mine);
                     int pos = n + (int)(incl - mine);
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        if ((cbd >> j) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
-                        if ((cbd >> (4 + j)) & 1u) mylist[pos++] = (unsigned short)(0x8000u | (rr << 8) | (4 * lane + j));
+                        const int bit = (j & 1) + 16 * (j >> 1);
+                        if ((cbd >> bit) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
+                        if ((cbd >> (bit + 2)) & 1u) mylist[pos++] = (unsigned short)(0x8000u | (rr << 8) | (4 * lane + j));
                     }
                     n += __builtin_amdgcn_readlane((int)incl, 63);
                 }
