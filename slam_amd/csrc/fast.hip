@@ -29,6 +29,9 @@ constexpr int FAST_PPITCH = FAST_CW + 8;        // pixel tile pitch: 4 more colu
 constexpr int FAST_TH = 30;                     // output rows per tile
 constexpr int FAST_SR = FAST_TH + 2;            // score rows: one halo row above and below; 8 per wavefront
 constexpr int FAST_PR = FAST_TH + 8;            // pixel rows
+#ifndef FAST_DENSE_LANES
+#define FAST_DENSE_LANES 24                     // lanes of a row with a candidate after half the pair test: beyond, the other half runs
+#endif
 constexpr int FAST_LIST = 768;                  // candidate slots per wavefront; a row adds at most 2 * FAST_CW (one per pixel and polarity)
 
 struct FastPlan {
@@ -194,40 +197,56 @@ __device__ __forceinline__ void fast_pair_test(const unsigned* A, const unsigned
 // and ring positions that meet on it (dy = -1, 0, +1 use the same four, dy = +-3 and dy = +-2 overlap in two), so the
 // 8 rows of a wavefront need about 100 byte picks instead of 272.  `q`: the pixel row, whose window rows are q .. q + 6.
 template <int Q>
-__device__ __forceinline__ void fast_pair_test_shared(const fast_u2 (&S)[FAST_SR / 4 + 6][8], int t, unsigned& flags) {
+__device__ __forceinline__ void fast_pair_test_shared(const fast_u2 (&S)[FAST_SR / 4 + 6][8], int t, unsigned inside, unsigned& flags) {
     // Pixel values (0..255) in 16-bit halves are also positive subnormal half floats, which order like their bit
     // patterns: the three-operand packed minimum / maximum of gfx950 (half-float only) halves the reduction trees.
-    unsigned mn_of_mx[2], mx_of_mn[2];
-#pragma unroll
-    for (int o = 0; o < 2; o++) {
-        unsigned mx[8], mn[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const fast_u2 r0 = S[Q + 3 + ring_dy(k)][ring_dx(k) + o + 3];
-            const fast_u2 r1 = S[Q + 3 + ring_dy(k + 8)][ring_dx(k + 8) + o + 3];
-            mx[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(r0, r1));
-            mn[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(r0, r1));
-        }
-        unsigned a = pk_min3_h(mx[0], mx[1], mx[2]);
-        a = pk_min3_h(a, mx[3], mx[4]);
-        a = pk_min3_h(a, mx[5], mx[6]);
-        mn_of_mx[o] = pk_min_u16(a, mx[7]);
-        unsigned b = pk_max3_h(mn[0], mn[1], mn[2]);
-        b = pk_max3_h(b, mn[3], mn[4]);
-        b = pk_max3_h(b, mn[5], mn[6]);
-        mx_of_mn[o] = pk_max_u16(b, mn[7]);
-    }
     // Flags of the lane's four pixels in one register: bright pixel j at bit (j & 1) + 16 * (j >> 1), dark two bits
     // higher.  Saturating differences are non-zero exactly when the comparison holds; min(.., 1) makes them flags.
     // (Written as instructions: left to itself the compiler turns each flag into a compare and a select.)
     const unsigned T2 = (unsigned)t * 0x10001u, ONE = 0x10001u;     // no carry between the halves: pixel + t < 2^16
+    unsigned mn_of_mx[2], mx_of_mn[2], v[2];
+    // the even pairs first (the compass points and the diagonals) ...
     flags = 0;
 #pragma unroll
     for (int o = 0; o < 2; o++) {
-        const unsigned v = __builtin_bit_cast(unsigned, S[Q + 3][o + 3]);
-        const unsigned nb = pk_min_u16(pk_sub_sat_u16(mn_of_mx[o], v + T2), ONE);
-        const unsigned nd = pk_min_u16(pk_sub_sat_u16(v, mx_of_mn[o] + T2), ONE);
+        unsigned mx[4], mn[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const fast_u2 r0 = S[Q + 3 + ring_dy(2 * k)][ring_dx(2 * k) + o + 3];
+            const fast_u2 r1 = S[Q + 3 + ring_dy(2 * k + 8)][ring_dx(2 * k + 8) + o + 3];
+            mx[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(r0, r1));
+            mn[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(r0, r1));
+        }
+        mn_of_mx[o] = pk_min_u16(pk_min3_h(mx[0], mx[1], mx[2]), mx[3]);
+        mx_of_mn[o] = pk_max_u16(pk_max3_h(mn[0], mn[1], mn[2]), mn[3]);
+        v[o] = __builtin_bit_cast(unsigned, S[Q + 3][o + 3]);
+        const unsigned nb = pk_min_u16(pk_sub_sat_u16(mn_of_mx[o], v[o] + T2), ONE);
+        const unsigned nd = pk_min_u16(pk_sub_sat_u16(v[o], mx_of_mn[o] + T2), ONE);
         flags |= (nb << o) | (nd << (2 + o));
+    }
+    flags &= inside;
+    // ... and the odd pairs only where the even ones leave many candidates (wave-uniform): a candidate that the full
+    // test would have dropped costs one exact score, about three times a pixel's share of this test, so the second half
+    // pays on dense rows and is skipped on sparse ones.  Either way the flags are a superset of the corners.
+    if (__popcll(__ballot(flags != 0u)) > FAST_DENSE_LANES) {
+        unsigned f2 = 0;
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            unsigned mx[4], mn[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const fast_u2 r0 = S[Q + 3 + ring_dy(2 * k + 1)][ring_dx(2 * k + 1) + o + 3];
+                const fast_u2 r1 = S[Q + 3 + ring_dy(2 * k + 9)][ring_dx(2 * k + 9) + o + 3];
+                mx[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(r0, r1));
+                mn[k] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(r0, r1));
+            }
+            const unsigned a = pk_min3_h(pk_min3_h(mx[0], mx[1], mx[2]), mx[3], mn_of_mx[o]);
+            const unsigned b = pk_max3_h(pk_max3_h(mn[0], mn[1], mn[2]), mn[3], mx_of_mn[o]);
+            const unsigned nb = pk_min_u16(pk_sub_sat_u16(a, v[o] + T2), ONE);
+            const unsigned nd = pk_min_u16(pk_sub_sat_u16(v[o], b + T2), ONE);
+            f2 |= (nb << o) | (nd << (2 + o));
+        }
+        flags &= f2;
     }
 }
 
@@ -245,10 +264,10 @@ __device__ __forceinline__ void fast_rows_shared(fast_u2 (&S)[FAST_SR / 4 + 6][8
         }
         const int y = y_first + Q;
         unsigned flags = 0;
-        if (y >= 3 && y < h - 3 && !skip) fast_pair_test_shared<Q>(S, t, flags);      // wave-uniform condition
+        if (y >= 3 && y < h - 3 && !skip) fast_pair_test_shared<Q>(S, t, inside, flags);      // wave-uniform condition
         // four rows per register: row Q's flags sit 4 * (Q & 3) bits up, in bits 0..15 and 16..31 alike
-        if (Q < 4) cand_lo |= (flags & inside) << (4 * (Q & 3));
-        else cand_hi |= (flags & inside) << (4 * (Q & 3));
+        if (Q < 4) cand_lo |= flags << (4 * (Q & 3));
+        else cand_hi |= flags << (4 * (Q & 3));
         fast_rows_shared<Q + 1>(S, px, ry0, lane, y_first, h, t, skip, inside, cand_lo, cand_hi);
     }
 }
@@ -447,20 +466,24 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
                             M[q] = *reinterpret_cast<const fl_u32*>(row + 4 * lane - 4 + 4 * q);
                             D[q] = *reinterpret_cast<const fl_u32*>(row + FAST_CW + 4 * lane - 4 + 4 * q);
                         }
-                        // two pixels per operation, as in phase 1: pixels j = o and o + 2 as 16-bit halves; a score is
-                        // kept when it exceeds the largest of its 8 neighbours (a zero score never does)
+                        // two pixels per operation, as in phase 1: pixels j = o and o + 2 as 16-bit halves, shifted pairs
+                        // shared between the neighbours (s = dx + o); a score is kept when it exceeds the largest of its
+                        // 8 neighbours (a zero score never does).  Scores are below 0x400: see pk_max3_h.
+                        unsigned Us[4], Ms[4], Ds[4];
+#pragma unroll
+                        for (int sft = -1; sft <= 2; sft++) {
+                            Us[sft + 1] = __builtin_bit_cast(unsigned, ring_pair(U[0], U[1], U[2], sft, 0));
+                            Ms[sft + 1] = __builtin_bit_cast(unsigned, ring_pair(M[0], M[1], M[2], sft, 0));
+                            Ds[sft + 1] = __builtin_bit_cast(unsigned, ring_pair(D[0], D[1], D[2], sft, 0));
+                        }
 #pragma unroll
                         for (int o = 0; o < 2; o++) {
-                            const fast_u2 s2 = ring_pair(M[0], M[1], M[2], 0, o);
-                            fast_u2 nb = __builtin_elementwise_max(ring_pair(M[0], M[1], M[2], -1, o), ring_pair(M[0], M[1], M[2], 1, o));
-#pragma unroll
-                            for (int dx = -1; dx <= 1; dx++) {
-                                nb = __builtin_elementwise_max(nb, ring_pair(U[0], U[1], U[2], dx, o));
-                                nb = __builtin_elementwise_max(nb, ring_pair(D[0], D[1], D[2], dx, o));
-                            }
-                            const fast_u2 hit = __builtin_elementwise_sub_sat(s2, nb);
-                            if (hit.x != 0) keep |= 1u << o;
-                            if (hit.y != 0) keep |= 4u << o;
+                            const unsigned nbu = pk_max3_h(Us[o], Us[o + 1], Us[o + 2]);
+                            const unsigned nbd = pk_max3_h(Ds[o], Ds[o + 1], Ds[o + 2]);
+                            const unsigned nb = pk_max3_h(nbu, nbd, pk_max_u16(Ms[o], Ms[o + 2]));
+                            const unsigned hit = pk_sub_sat_u16(Ms[o + 1], nb);
+                            if (hit & 0xffffu) keep |= 1u << o;
+                            if (hit >> 16) keep |= 4u << o;
                         }
                     } else {
 #pragma unroll
