@@ -115,6 +115,11 @@ __device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ unsigned pk_mad_u16(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
     unsigned r;
     asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -135,17 +140,19 @@ __device__ __forceinline__ unsigned pk_max3_h(unsigned a, unsigned b, unsigned c
 
 // cv::FAST's cornerScore "A" value of two candidates at once, one per 16-bit half: max over the 16 arcs of 9 contiguous
 // ring pixels of the arc minimum of (ring - v) for a candidate of the bright polarity, of (v - ring) for the dark one.
-// A dark candidate is turned into a bright one by complementing its bytes (255 - x = x ^ 0xFF keeps differences):
 // xm holds 0xFF in the halves of dark candidates.  The differences are kept with a bias of 256 (1..511: below 0x400, see
 // pk_min3_h): arc minima as min3 of min3 (9 = 3 x 3), their maximum by a max3 tree.
 __device__ __forceinline__ fast_s2 fast_arc_scores2(const fl_u8* p1, const fl_u8* p2, int pitch, unsigned xm) {
-    const unsigned V = ((unsigned)p1[0] | ((unsigned)p2[0] << 16)) ^ xm;
-    const unsigned W = 0x01000100u - V;                  // 256 - v per half, no borrow between the halves
+    // difference + 256 = ring * s + (256 - v * s) per half, s = +1 (bright) or -1 (dark), modulo 2^16: one packed
+    // multiply-add per ring pixel pair.  sg holds 1 or 0xFFFF in the halves.
+    const unsigned V = (unsigned)p1[0] | ((unsigned)p2[0] << 16);
+    const unsigned sg = 0x00010001u | xm | (xm << 8);      // xm is 0xFF in the halves of dark candidates
+    const unsigned W = pk_mad_u16(V, sg ^ 0xFFFEFFFEu, 0x01000100u);     // 256 - v * s: multiply by -s (1 <-> 0xFFFF)
     unsigned e[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int o = ring_dy(k) * pitch + ring_dx(k);
-        e[k] = (((unsigned)p1[o] | ((unsigned)p2[o] << 16)) ^ xm) + W;
+        e[k] = pk_mad_u16((unsigned)p1[o] | ((unsigned)p2[o] << 16), sg, W);
     }
     unsigned m3[16], m9[16];
 #pragma unroll
