@@ -8,6 +8,26 @@ namespace slamhip {
 
 // One context per host thread, created on first use and deliberately never destroyed: at process
 // exit the HIP runtime may already be shutting down when thread-local destructors run.
+namespace {
+Error& error_slot() {
+    static thread_local Error e = {SLAM_HIP_OK, std::string()};
+    return e;
+}
+}  // namespace
+
+const Error& last_error() { return error_slot(); }
+void clear_error() { error_slot().code = SLAM_HIP_OK; error_slot().message.clear(); }
+
+bool failed(int rc, const char* what, const char* detail) {
+    if (rc >= 0) return false;
+    Error& e = error_slot();
+    e.code = rc;
+    e.message = std::string(what) + ": " + (detail ? detail : "");
+    return true;
+}
+
+// nullptr when no context can be made (no device, out of memory): every ABI call then answers SLAM_HIP_EINVAL, which
+// the callers below turn into their sentinel results.
 slam_ctx* context() {
     static thread_local slam_ctx* ctx = nullptr;
     if (!ctx) {
@@ -15,15 +35,16 @@ slam_ctx* context() {
         const int dev = d ? std::atoi(d) : 0;
         slam_ctx* c = nullptr;
         const int rc = slam_hip_create(dev, &c);
-        if (rc != SLAM_HIP_OK)
-            throw std::runtime_error(std::string("slam_hip_create: ") + slam_hip_last_error_string(nullptr));
+        if (failed(rc, "slam_hip_create", slam_hip_last_error_string(nullptr))) return nullptr;
         ctx = c;
     }
     return ctx;
 }
 
-void check(int rc, const char* what) {
-    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + slam_hip_last_error_string(context()));
+bool failed(int rc, const char* what) {
+    if (rc >= 0) return false;
+    slam_ctx* c = context();
+    return failed(rc, what, c ? slam_hip_last_error_string(c) : "no device context");
 }
 
 // Live ImagePyramid mirrors of the calling thread: matchFeatureInArea looks an image up here, so that a search on a
@@ -39,7 +60,10 @@ std::vector<const ImagePyramid<byte>*>& live_pyramids() {
 ImagePyramid<byte>::ImagePyramid(const mati& imFullSize, const std::vector<float>& subs) : subsamples(subs) {
     slam_ctx* ctx = slamhip::context();
     const int w = imFullSize.cols, h = imFullSize.rows;
-    slamhip::check(slam_hip_pyramid_create(ctx, w, h, (int)subs.size(), subs.data(), 1, &pyr_), "ImagePyramid");
+    if (slamhip::failed(slam_hip_pyramid_create(ctx, w, h, (int)subs.size(), subs.data(), 1, &pyr_), "ImagePyramid")) {
+        pyr_ = nullptr;                 // ok() is false, images stays empty
+        return;
+    }
     int rc = slam_hip_pyramid_build(ctx, pyr_, imFullSize.data, imFullSize.step, 0);
     for (size_t i = 0; rc == SLAM_HIP_OK && i < subs.size(); i++) {
         slam_level_desc d;
@@ -49,10 +73,11 @@ ImagePyramid<byte>::ImagePyramid(const mati& imFullSize, const std::vector<float
         rc = slam_hip_pyramid_download(ctx, pyr_, (int)i, 0, lvl.data, lvl.step);
         images.push_back(lvl);
     }
-    if (rc != SLAM_HIP_OK) {
+    if (slamhip::failed(rc, "ImagePyramid")) {
         slam_hip_pyramid_destroy(ctx, pyr_);
         pyr_ = nullptr;
-        slamhip::check(rc, "ImagePyramid");
+        images.clear();
+        return;
     }
     slamhip::live_pyramids().push_back(this);
 }
@@ -100,37 +125,46 @@ cv::Point2i SLAM::matchFeatureInArea(const cv::Mat_<byte>& im, const cv::Mat_<by
         job.amask_off = areaMask ? (int64_t)aoff : -1;
         job.stride = stride; job.use_exact_area_mask = useExactAreaMask ? 1 : 0;
         job.score_off = -1;
-        slamhip::check(slam_hip_match_batch(slamhip::context(), live[k]->device(), &job, 1, blob.data(), blob.size(), &r), "matchFeatureInArea");
-        if (r.status != SLAM_HIP_OK) throw std::invalid_argument("matchFeatureInArea: job rejected by the device");
+        if (slamhip::failed(slam_hip_match_batch(slamhip::context(), live[k]->device(), &job, 1, blob.data(), blob.size(), &r), "matchFeatureInArea") ||
+            slamhip::failed(r.status, "matchFeatureInArea", "job rejected by the device")) {
+            response = -1.f;            // the sentinel of matching.cpp:26-30
+            return cv::Point2i(0, 0);
+        }
         response = r.response;
         return cv::Point2i(r.x, r.y);
     }
-    slamhip::check(slam_hip_match_feature_in_area(
-                       slamhip::context(), im.data, im.cols, im.rows, im.step, patch.data, patch.cols, patch.rows,
-                       patch.step, patchMask ? patchMask->data : nullptr, patchMask ? patchMask->step : 0,
-                       areaRect.x, areaRect.y, areaRect.width, areaRect.height,
-                       areaMask ? areaMask->data : nullptr, areaMask ? areaMask->step : 0, stride,
-                       useExactAreaMask ? 1 : 0, nullptr, &r),
-                   "matchFeatureInArea");
+    if (slamhip::failed(slam_hip_match_feature_in_area(
+                            slamhip::context(), im.data, im.cols, im.rows, im.step, patch.data, patch.cols, patch.rows,
+                            patch.step, patchMask ? patchMask->data : nullptr, patchMask ? patchMask->step : 0,
+                            areaRect.x, areaRect.y, areaRect.width, areaRect.height,
+                            areaMask ? areaMask->data : nullptr, areaMask ? areaMask->step : 0, stride,
+                            useExactAreaMask ? 1 : 0, nullptr, &r),
+                        "matchFeatureInArea")) {
+        response = -1.f;                // the sentinel of matching.cpp:26-30
+        return cv::Point2i(0, 0);
+    }
     response = r.response;
     return cv::Point2i(r.x, r.y);
 }
 
 namespace {
 
-// Packs templates and masks row by row into one blob and fills the job table.
-void pack_jobs(const std::vector<SLAM::Projection>& f, float threshold, int stride,
+// Packs templates and masks row by row into one blob and fills the job table.  false (error recorded): a projection
+// whose template and mask differ in size.
+bool pack_jobs(const std::vector<SLAM::Projection>& f, float threshold, int stride,
                std::vector<slam_track_job>& jobs, std::vector<uint8_t>& blob) {
     size_t total = 0;
-    for (const auto& p : f) total += 2 * (size_t)p.proj.rows * p.proj.cols;
+    for (const auto& p : f) {
+        if (p.proj.cols > 0 && p.proj.rows > 0 && (p.projMask.cols != p.proj.cols || p.projMask.rows != p.proj.rows))
+            return !slamhip::failed(SLAM_HIP_EINVAL, "Projection", "proj and projMask differ in size");
+        total += 2 * (size_t)p.proj.rows * p.proj.cols;
+    }
     blob.resize(total ? total : 1);
     jobs.resize(f.size());
     size_t off = 0;
     for (size_t i = 0; i < f.size(); i++) {
         const SLAM::Projection& p = f[i];
         const int pw = p.proj.cols, ph = p.proj.rows;
-        if (pw > 0 && ph > 0 && (p.projMask.cols != pw || p.projMask.rows != ph))
-            throw std::invalid_argument("Projection: proj and projMask differ in size");
         slam_track_job& j = jobs[i];
         std::memset(&j, 0, sizeof(j));
         j.frame = 0; j.projw = pw; j.projh = ph;
@@ -142,6 +176,7 @@ void pack_jobs(const std::vector<SLAM::Projection>& f, float threshold, int stri
         off += (size_t)pw * ph;
         j.px = p.p2d.x; j.py = p.p2d.y; j.threshold = threshold; j.stride = stride;
     }
+    return true;
 }
 
 }  // namespace
@@ -150,11 +185,13 @@ cv::Point2i SLAM::Feature::track(const ImagePyramid<byte>& pyramid, const Projec
                                  float& response) {
     std::vector<slam_track_job> jobs;
     std::vector<uint8_t> blob;
-    pack_jobs(std::vector<Projection>(1, p), threshold, stride, jobs, blob);
     slam_track_result r;
-    slamhip::check(slam_hip_track_batch(slamhip::context(), pyramid.device(), jobs.data(), 1, blob.data(), blob.size(), &r),
-                   "Feature::track");
-    if (r.status != SLAM_HIP_OK) throw std::invalid_argument("Feature::track: job rejected by the device");
+    if (!pack_jobs(std::vector<Projection>(1, p), threshold, stride, jobs, blob) ||
+        slamhip::failed(slam_hip_track_batch(slamhip::context(), pyramid.device(), jobs.data(), 1, blob.data(), blob.size(), &r), "Feature::track") ||
+        slamhip::failed(r.status, "Feature::track", "job rejected by the device")) {
+        response = -1.f;                // the sentinel of feature.cpp:112-115
+        return cv::Point2i(-1, -1);
+    }
     response = r.response;
     return cv::Point2i(r.x, r.y);
 }
@@ -193,22 +230,24 @@ bool setup_projection(const SLAM::Feature& f, const SLAM::CameraState& state, co
     location = cv::Rect(0, 0, 0, 0);
     if (f.descriptor.cols <= 0 || f.descriptor.rows <= 0) return false;              // feature.cpp:56-59
     if (f.B.rows != 4 || f.B.cols != 3 || state.P.rows != 3 || state.P.cols != 4 || p3d.rows != 3)
-        throw std::invalid_argument("Feature::project: B must be 4x3, state.P 3x4, p3d 3x1");
+        return !slamhip::failed(SLAM_HIP_EINVAL, "Feature::project", "B must be 4x3, state.P 3x4, p3d 3x1");
     for (int r = 0; r < 3; r++) f.B(r, 2) = p3d(r, 0);                                // feature.cpp:61
     float P[12], B[12], p[3];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) P[r * 4 + c] = state.P(r, c);
     for (int r = 0; r < 4; r++) for (int c = 0; c < 3; c++) B[r * 3 + c] = f.B(r, c);
     for (int r = 0; r < 3; r++) p[r] = p3d(r, 0);
     int32_t loc[4], valid = 0;
-    if (slam_hip_project_setup(P, B, p, f.descriptor.cols, f.descriptor.rows, loc, job.m, &valid) != SLAM_HIP_OK)
-        throw std::invalid_argument("Feature::project: bad arguments");
+    if (slamhip::failed(slam_hip_project_setup(P, B, p, f.descriptor.cols, f.descriptor.rows, loc, job.m, &valid), "Feature::project", "bad arguments"))
+        return false;
     location = cv::Rect(loc[0], loc[1], loc[2], loc[3]);
     if (!valid) return false;
     job.dw = f.descriptor.cols; job.dh = f.descriptor.rows; job.ow = loc[2]; job.oh = loc[3];
     return true;
 }
 
-void track_features(const ImagePyramid<byte>& pyramid, const SLAM::CameraState& state,
+// false (error recorded): the device pass failed or rejected a job; `res` then holds the empty-projection sentinel
+// of feature.cpp:112-115 for every feature.
+bool track_features(const ImagePyramid<byte>& pyramid, const SLAM::CameraState& state,
                     const SLAM::Feature* const* feats, const matf* const* p3ds, size_t n, float threshold, int stride,
                     std::vector<slam_track_result>& res) {
     std::vector<slam_warp_job> wj(n);
@@ -226,11 +265,15 @@ void track_features(const ImagePyramid<byte>& pyramid, const SLAM::CameraState& 
     }
     if (blob.empty()) blob.push_back(0);
     res.resize(n);
-    slamhip::check(slam_hip_project_track_batch(slamhip::context(), pyramid.device(), wj.data(), tj.data(), (int)n, blob.data(),
-                                                blob.size(), res.data()),
-                   "Feature::track");
-    for (size_t i = 0; i < n; i++)
-        if (res[i].status != SLAM_HIP_OK) throw std::invalid_argument("Feature::track: job rejected by the device");
+    bool bad = slamhip::failed(slam_hip_project_track_batch(slamhip::context(), pyramid.device(), wj.data(), tj.data(), (int)n, blob.data(),
+                                                            blob.size(), res.data()),
+                               "Feature::track");
+    for (size_t i = 0; !bad && i < n; i++) bad = slamhip::failed(res[i].status, "Feature::track", "job rejected by the device");
+    if (bad) {
+        const slam_track_result none = {-1, -1, -1.f, 0.f, 0.f, 0, SLAM_HIP_EINVAL};
+        res.assign(n, none);
+    }
+    return !bad;
 }
 
 }  // namespace
@@ -245,9 +288,13 @@ matb SLAM::Feature::project(const CameraState& state, const matf& p3d, matb& mas
     matb proj(location.height, location.width);
     mask = matb(location.height, location.width);
     int32_t loc[4], valid = 0;
-    slamhip::check(slam_hip_project(slamhip::context(), descriptor.data, descriptor.cols, descriptor.rows, descriptor.step, P, Bm, p,
-                                    proj.data, mask.data, (size_t)location.width * location.height, loc, &valid),
-                   "Feature::project");
+    if (slamhip::failed(slam_hip_project(slamhip::context(), descriptor.data, descriptor.cols, descriptor.rows, descriptor.step, P, Bm, p,
+                                         proj.data, mask.data, (size_t)location.width * location.height, loc, &valid),
+                        "Feature::project")) {
+        mask = matb();
+        location = cv::Rect(0, 0, 0, 0);
+        return matb();                  // what an empty projection returns (feature.cpp:56-59)
+    }
     return proj;
 }
 
@@ -265,8 +312,8 @@ void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const CameraState& sta
                        const std::vector<matf>& p3ds, std::vector<Match>& matches, float threshold, int stride,
                        std::vector<float>* responses) {
     matches.clear();
-    if (features.size() != p3ds.size()) throw std::invalid_argument("matchPoints: one p3d per feature");
     if (responses) responses->assign(features.size(), -1.f);
+    if (features.size() != p3ds.size()) { slamhip::failed(SLAM_HIP_EINVAL, "matchPoints", "one p3d per feature"); return; }
     if (features.empty()) return;
     std::vector<const Feature*> fp(features.size());
     std::vector<const matf*> pp(features.size());
@@ -287,13 +334,15 @@ void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Proj
     if (features.empty()) return;
     std::vector<slam_track_job> jobs;
     std::vector<uint8_t> blob;
-    pack_jobs(features, threshold, stride, jobs, blob);
+    if (!pack_jobs(features, threshold, stride, jobs, blob)) return;
     std::vector<slam_track_result> res(features.size());
-    slamhip::check(slam_hip_track_batch(slamhip::context(), pyramid.device(), jobs.data(), (int)jobs.size(), blob.data(),
-                                        blob.size(), res.data()),
-                   "matchPoints");
+    if (slamhip::failed(slam_hip_track_batch(slamhip::context(), pyramid.device(), jobs.data(), (int)jobs.size(), blob.data(),
+                                             blob.size(), res.data()),
+                        "matchPoints"))
+        return;
+    for (size_t i = 0; i < res.size(); i++)
+        if (slamhip::failed(res[i].status, "matchPoints", "job rejected by the device")) return;      // no matches at all
     for (size_t i = 0; i < res.size(); i++) {
-        if (res[i].status != SLAM_HIP_OK) throw std::invalid_argument("matchPoints: job rejected by the device");
         if (responses) (*responses)[i] = res[i].response;
         if (res[i].response > threshold)      // matching.cpp:262
             matches.push_back(Match(cv::Point2f((float)res[i].x, (float)res[i].y), (int)i));
@@ -305,23 +354,25 @@ void SLAM::matchPointsGated(const ImagePyramid<byte>& pyramid, const std::vector
                             float threshold, int stride, std::vector<float>* responses) {
     matches.clear();
     if (responses) responses->assign(features.size(), -1.f);
-    if (features.size() != covariances.size()) throw std::invalid_argument("matchPointsGated: one covariance per feature");
+    if (features.size() != covariances.size()) { slamhip::failed(SLAM_HIP_EINVAL, "matchPointsGated", "one covariance per feature"); return; }
     if (features.empty()) return;
     std::vector<slam_track_job> jobs;
     std::vector<uint8_t> blob;
-    pack_jobs(features, threshold, stride, jobs, blob);
+    if (!pack_jobs(features, threshold, stride, jobs, blob)) return;
     const float areaRes = 1.f / pyramid.subsamples[pyramid.nSubs() - 1];
     std::vector<slam_ellipse_job> windows(features.size());
     for (size_t i = 0; i < features.size(); i++) {
         const float cov[3] = {covariances[i][0], covariances[i][1], covariances[i][2]};
-        slamhip::check(slam_hip_ellipse_setup(jobs[i].px, jobs[i].py, cov, gate, areaRes, &windows[i]), "matchPointsGated");
+        if (slamhip::failed(slam_hip_ellipse_setup(jobs[i].px, jobs[i].py, cov, gate, areaRes, &windows[i]), "matchPointsGated", "bad covariance or gate")) return;
     }
     std::vector<slam_track_result> res(features.size());
-    slamhip::check(slam_hip_track_ellipse_batch(slamhip::context(), pyramid.device(), jobs.data(), windows.data(),
-                                                (int)jobs.size(), blob.data(), blob.size(), res.data()),
-                   "matchPointsGated");
+    if (slamhip::failed(slam_hip_track_ellipse_batch(slamhip::context(), pyramid.device(), jobs.data(), windows.data(),
+                                                     (int)jobs.size(), blob.data(), blob.size(), res.data()),
+                        "matchPointsGated"))
+        return;
+    for (size_t i = 0; i < res.size(); i++)
+        if (slamhip::failed(res[i].status, "matchPointsGated", "job rejected by the device")) return;
     for (size_t i = 0; i < res.size(); i++) {
-        if (res[i].status != SLAM_HIP_OK) throw std::invalid_argument("matchPointsGated: job rejected by the device");
         if (responses) (*responses)[i] = res[i].response;
         if (res[i].response > threshold)
             matches.push_back(Match(cv::Point2f((float)res[i].x, (float)res[i].y), (int)i));
@@ -338,7 +389,7 @@ void SLAM::matchLines(const ImagePyramid<byte>& pyramid, const std::vector<LineS
     std::vector<uint8_t> blob;
     for (size_t i = 0; i < lines.size(); i++) {
         const LineSearch& l = lines[i];
-        if (l.binCenters.size() != l.binRadii.size()) throw std::invalid_argument("matchLines: one radius per bin centre");
+        if (l.binCenters.size() != l.binRadii.size()) { slamhip::failed(SLAM_HIP_EINVAL, "matchLines", "one radius per bin centre"); return; }
         slam_line_job& j = jobs[i];
         std::memset(&j, 0, sizeof(j));
         j.desc_off = (int64_t)blob.size();
@@ -354,12 +405,14 @@ void SLAM::matchLines(const ImagePyramid<byte>& pyramid, const std::vector<LineS
     }
     if (blob.empty()) blob.push_back(0);
     std::vector<slam_track_result> res(lines.size());
-    slamhip::check(slam_hip_match_lines_batch(slamhip::context(), pyramid.device(), jobs.data(), (int)jobs.size(),
-                                              circles.empty() ? nullptr : circles.data(), (int)(circles.size() / 3), begin.data(),
-                                              blob.data(), blob.size(), res.data()),
-                   "matchLines");
+    if (slamhip::failed(slam_hip_match_lines_batch(slamhip::context(), pyramid.device(), jobs.data(), (int)jobs.size(),
+                                                   circles.empty() ? nullptr : circles.data(), (int)(circles.size() / 3), begin.data(),
+                                                   blob.data(), blob.size(), res.data()),
+                        "matchLines"))
+        return;
+    for (size_t i = 0; i < res.size(); i++)
+        if (slamhip::failed(res[i].status, "matchLines", "job rejected by the device")) return;
     for (size_t i = 0; i < res.size(); i++) {
-        if (res[i].status != SLAM_HIP_OK) throw std::invalid_argument("matchLines: job rejected by the device");
         if (responses) (*responses)[i] = res[i].response;
         if (res[i].response > threshold)      // matching.cpp:288
             matches.push_back(Match(cv::Point2f((float)res[i].x, (float)res[i].y), (int)i));
@@ -388,8 +441,7 @@ matb SLAM::lineAreaMask(const LineSearch& l) {
     if (rc == SLAM_HIP_OK) rc = slam_hip_memcpy_d2h(ctx, &st, (uint8_t*)d_j + sizeof(job), 4);
     if (rc == SLAM_HIP_OK && st == SLAM_HIP_OK) rc = slam_hip_memcpy_d2h(ctx, out.data, d_m, npix);
     slam_hip_free(ctx, d_c); slam_hip_free(ctx, d_j); slam_hip_free(ctx, d_m);
-    slamhip::check(rc, "lineAreaMask");
-    if (st != SLAM_HIP_OK) throw std::invalid_argument("lineAreaMask: negative radius");
+    if (slamhip::failed(rc, "lineAreaMask") || slamhip::failed(st, "lineAreaMask", "negative radius")) return matb();
     return out;
 }
 
@@ -409,11 +461,12 @@ std::vector<int> SLAM::selectNewPoints(const matb& im, const std::vector<cv::Key
     const size_t one = (size_t)(2 * rx + 1) * (2 * ry + 1);
     std::vector<uint8_t> desc(descriptors ? one * (size_t)n : 0);
     std::vector<slam_desc_result> res(descriptors ? (size_t)n : 0);
-    slamhip::check(slam_hip_add_new_points(slamhip::context(), im.data, im.cols, im.rows, im.step, kps.data(), (int)kps.size(), 1,
-                                           occ.empty() ? nullptr : occ.data(), (int)(occ.size() / 2), n, minDist, rx, ry,
-                                           sel.data(), &nsel, nullptr, descriptors ? desc.data() : nullptr, desc.size(),
-                                           descriptors ? res.data() : nullptr),
-                   "selectNewPoints");
+    if (slamhip::failed(slam_hip_add_new_points(slamhip::context(), im.data, im.cols, im.rows, im.step, kps.data(), (int)kps.size(), 1,
+                                                occ.empty() ? nullptr : occ.data(), (int)(occ.size() / 2), n, minDist, rx, ry,
+                                                sel.data(), &nsel, nullptr, descriptors ? desc.data() : nullptr, desc.size(),
+                                                descriptors ? res.data() : nullptr),
+                        "selectNewPoints"))
+        return out;                     // no point selected
     out.assign(sel.begin(), sel.begin() + nsel);
     if (descriptors)
         for (int i = 0; i < nsel; i++) {
@@ -433,7 +486,7 @@ void SLAM::getSortedKeyPoints(const matb& im, size_t nMinPts, std::vector<cv::Ke
         int32_t n = 0;
         float thr = fastThreshold;
         const int rc = slam_hip_get_sorted_keypoints(ctx, im.data, im.cols, im.rows, im.step, nMinPts, &thr, kps.data(), cap, &n);
-        slamhip::check(rc, "getSortedKeyPoints");
+        if (rc != SLAM_HIP_ECAP && slamhip::failed(rc, "getSortedKeyPoints")) { out.clear(); return; }
         if (n > cap) { cap = n; continue; }   // the list was cut at cap: run again with room for all
         fastThreshold = thr;
         out.clear();

@@ -8,11 +8,12 @@
 //   SLAM::matchLines               SLAM.hpp:108-109, matching.cpp:271-310 (the image work of LineFeature::track)
 //   SLAM::getSortedKeyPoints       SLAM.hpp:118-119, new_point.cpp:113-127
 //   SLAM::matchPoints              SLAM.hpp:106-107, matching.cpp:230-269 (batched over features)
-// Device errors (no GPU, failed allocation) are reported by std::runtime_error; the reference's own
-// sentinels (response -1 and (0,0) for an off-image window, (-1,-1) for an empty projection) are kept.
+// Nothing here throws, as nothing in the reference does: a device error (no GPU, failed allocation) or a rejected
+// argument gives the call's own sentinel - response -1 and (0,0) from matchFeatureInArea (matching.cpp:26-30), (-1,-1)
+// and -1 from Feature::track (feature.cpp:112-115), no matches, no keypoints, an empty Mat - and leaves its code and
+// message in slamhip::last_error() of the calling thread.
 #pragma once
 
-#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -24,10 +25,17 @@ typedef cv::Mat_<byte> matb;
 typedef cv::Mat_<float> matf;
 
 namespace slamhip {
-// The calling thread's context on device $SLAM_HIP_DEVICE (default 0), created on first use.
+// The calling thread's context on device $SLAM_HIP_DEVICE (default 0), created on first use; nullptr (error recorded)
+// when none can be made.
 slam_ctx* context();
-// Throws std::runtime_error carrying slam_hip_last_error_string when rc < 0.
-void check(int rc, const char* what);
+// The last failure of the calling thread: a SLAM_HIP_E* code (SLAM_HIP_OK: none since clear_error) and what failed.
+struct Error { int code; std::string message; };
+const Error& last_error();
+void clear_error();
+// rc < 0: records (rc, "what: detail") as the thread's last error and returns true.  Without `detail` the library's
+// slam_hip_last_error_string is used.
+bool failed(int rc, const char* what);
+bool failed(int rc, const char* what, const char* detail);
 }  // namespace slamhip
 
 template <typename imtype> class ImagePyramid;
@@ -49,6 +57,8 @@ public:
     ImagePyramid(const ImagePyramid&) = delete;
     ImagePyramid& operator=(const ImagePyramid&) = delete;
     size_t nSubs() const { return subsamples.size(); }
+    // false: the device pyramid could not be made (slamhip::last_error says why); images is then empty
+    bool ok() const { return pyr_ != nullptr; }
     const slam_pyr* device() const { return pyr_; }
     // index of the level whose host image `im` is (same buffer and shape), or -1
     int levelOf(const mati& im) const;

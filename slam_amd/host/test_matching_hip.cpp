@@ -6,6 +6,7 @@
 //   test_matching_hip [trials]      exit status 0 = every test passed
 #include <cmath>
 #include <cstdio>
+#include <exception>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
@@ -422,6 +423,35 @@ static bool test_line_calls_on_resident_levels() {
     return std::memcmp(&r, &rf, 4) == 0;
 }
 
+// The mirror never throws: a rejected argument gives the call's sentinel and leaves its code in slamhip::last_error().
+static bool test_errors_give_sentinels() {
+    bool ok = slamhip::last_error().code == SLAM_HIP_OK;         // none of the tests before this one failed silently
+    matb im(60, 80), patch(7, 7), pm(7, 7);
+    for (int i = 0; i < im.rows * im.cols; i++) im.data[i] = (byte)(i * 7);
+    for (int i = 0; i < 49; i++) { patch.data[i] = (byte)(i * 5); pm.data[i] = 1; }
+    pm(3, 3) = 2;                                                // the mask contract is {0, 1}: the library rejects it
+    float response = 0.5f;
+    const cv::Point2i p = SLAM::matchFeatureInArea(im, patch, &pm, cv::Rect(10, 10, 20, 20), nullptr, 1, response);
+    ok = ok && p.x == 0 && p.y == 0 && response == -1.f && slamhip::last_error().code == SLAM_HIP_EINVAL &&
+         !slamhip::last_error().message.empty();
+    slamhip::clear_error();
+    std::vector<float> subs(1, 1.f);
+    ImagePyramid<byte> pyr(im, subs);
+    ok = ok && pyr.ok();
+    SLAM::Projection pr;
+    pr.proj = patch; pr.projMask = matb(5, 5); pr.p2d = cv::Point2f(30.f, 30.f);
+    response = 0.5f;
+    const cv::Point2i q = SLAM::Feature::track(pyr, pr, 0.9f, 1, response);
+    ok = ok && q.x == -1 && q.y == -1 && response == -1.f && slamhip::last_error().code == SLAM_HIP_EINVAL;
+    slamhip::clear_error();
+    std::vector<SLAM::Match> matches(1, SLAM::Match(cv::Point2f(1.f, 1.f), 0));
+    std::vector<float> responses;
+    SLAM::matchPoints(pyr, std::vector<SLAM::Projection>(3, pr), matches, 0.9f, 1, &responses);
+    ok = ok && matches.empty() && responses.size() == 3 && responses[0] == -1.f && slamhip::last_error().code == SLAM_HIP_EINVAL;
+    slamhip::clear_error();
+    return ok && slamhip::last_error().code == SLAM_HIP_OK;
+}
+
 int main(int argc, char* argv[]) {
     const int nTrials = argc > 1 ? std::atoi(argv[1]) : 100;
     int failed = 0;
@@ -436,6 +466,7 @@ int main(int argc, char* argv[]) {
         DO_TEST("test_project_track", test_project_track());
         DO_TEST("test_match_lines", test_match_lines());
         DO_TEST("test_line_calls_resident", test_line_calls_on_resident_levels());
+        DO_TEST("test_errors_give_sentinels", test_errors_give_sentinels());
     } catch (const std::exception& e) {
         printf("exception: %s\n", e.what());
         return 2;

@@ -34,5 +34,5 @@ def test_reference_matching_tests_through_cpp_interface():
     r = subprocess.run([exe, os.environ.get("SLAM_PROP_TRIALS", "100")], capture_output=True, text=True, timeout=600)
     print(r.stdout, r.stderr)
     assert r.returncode == 0, "exit status %d\n" % r.returncode + r.stdout + r.stderr
-    assert r.stdout.count("passed") == 8
+    assert r.stdout.count("passed") == 9
     assert "resident level" in r.stdout          # LineFeature::track's calls ran on the resident pyramid levels (and were timed)
