@@ -48,7 +48,7 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     const char* nl = getenv("SLAM_HIP_NO_LEAN");
     c->no_lean = (nl && nl[0] == '1') ? 1 : 0;
     const char* wk = getenv("SLAM_HIP_WALK_LDS_KB");
-    if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) c->lean_lds_bytes = atoi(wk) * 1024;
+    if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) { c->lean_lds_bytes = atoi(wk) * 1024; c->lean_lds_user = 1; }
     const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");
     if (sk && atoi(sk) >= 4 && atoi(sk) <= 64) c->lean_match_lds_bytes = atoi(sk) * 1024;
     const char* sm = getenv("SLAM_HIP_SEARCH_LEAN_MIN");
@@ -100,6 +100,7 @@ extern "C" int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes) {
     if (bytes < 4096 || bytes > 65536 || (bytes & 1023))
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_walk_lds: %d not a multiple of 1024 in [4096, 65536]", bytes);
     ctx->lean_lds_bytes = bytes;
+    ctx->lean_lds_user = 1;
     return SLAM_HIP_OK;
 }
 

@@ -866,6 +866,7 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (ctx->force_direct || ctx->no_lean) {               // diagnostic settings: every job through the general kernel
+        ctx->lean_lds_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
                            ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
@@ -877,13 +878,49 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, ctx->d_queue);
 }
 
+// The entry points that take their job table from the host see the shapes before the launch: they size the lean walk
+// kernel's LDS to the largest need among the walks it could take (the host-side replica of lean_walk's fit check;
+// sizing only - the device decides), within [default, 24 KB], for that launch alone.  A budget set by the caller
+// (slam_hip_set_walk_lds, SLAM_HIP_WALK_LDS_KB) is left alone.
+void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs) {
+    ctx->lean_lds_once = 0;
+    if (ctx->lean_lds_user || !pyr) return;
+    const int nlev = pyr->dev.nlev;
+    int need = 0;
+    for (int i = 0; i < njobs; i++) {
+        const slam_track_job& jb = jobs[i];
+        if (jb.projw < 1 || jb.projh < 1 || jb.projw > 255 || jb.projh > 255 || jb.stride < 1 || jb.stride > 1024) continue;
+        const bool coarse_area = (jb.flags & SLAM_HIP_TRACK_COARSE_AREA) != 0;
+        int worst = 0;
+        for (int q = 0; q < nlev; q++) {
+            const slam_level_dev& lv = pyr->dev.lev[q];
+            const int tw = lv.sub == 1.f ? jb.projw : (int)((float)jb.projw / lv.sub);
+            const int th = lv.sub == 1.f ? jb.projh : (int)((float)jb.projh / lv.sub);
+            if (tw < 1 || th < 1) { worst = INT_MAX; break; }
+            float rad = lv.rad;
+            if (q == 0 && nlev > 1) rad = rad * (float)jb.stride;
+            int aw = (int)roundf(2.f * rad + 1.f), ah = aw;
+            if (coarse_area && q == nlev - 1) { aw = jb.aw; ah = jb.ah; }
+            if (aw < 1 || ah < 1 || aw > 255 || ah > 255) { worst = INT_MAX; break; }
+            const int step = q == 0 ? 1 : jb.stride;
+            const int nx = (aw + step - 1) / step, ny = (ah + step - 1) / step;
+            worst = std::max(worst, lean_need(tw, th, aw, ah, step, nx, ny, lv.sub != 1.f));
+        }
+        if (worst != INT_MAX && worst <= 24576) need = std::max(need, worst);      // larger walks go to the general kernel anyway
+    }
+    const int rounded = (need + 1023) / 1024 * 1024;
+    if (rounded > ctx->lean_lds_bytes) ctx->lean_lds_once = rounded;
+}
+
 // Lean kernel over all jobs, then the general kernel over whatever it queued.  `queue`: device words, SLAM_DEFER_LIST
 // + njobs of them.  Allocates nothing.
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
                       size_t blob_bytes, slam_track_result* d_out, int* queue) {
+    const int lds = ctx->lean_lds_once ? ctx->lean_lds_once : ctx->lean_lds_bytes;      // a host-table entry point may have sized this launch
+    ctx->lean_lds_once = 0;
     SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(track_lean_kernel, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), ctx->lean_lds_bytes, ctx->stream, pyr->dev, d_jobs, njobs,
-                       d_blob, (unsigned long long)blob_bytes, d_out, ctx->lean_lds_bytes, queue);
+    hipLaunchKernelGGL(track_lean_kernel, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), lds, ctx->stream, pyr->dev, d_jobs, njobs,
+                       d_blob, (unsigned long long)blob_bytes, d_out, lds, queue);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     // enough workgroups to fill the chip if everything was queued, few enough to start and end in microseconds if nothing was
     const int grid = njobs < 4096 ? njobs : 4096;
@@ -909,6 +946,7 @@ extern "C" int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr
     if (!q) return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch_noalloc: no scratch on device %d", ctx->device);
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (ctx->force_direct || ctx->no_lean) {               // diagnostic settings: every job through the general kernel, no queue
+        ctx->lean_lds_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
                            ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
@@ -941,6 +979,7 @@ extern "C" int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const sl
         return rc;
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[0], jobs, jb, hipMemcpyHostToDevice, ctx->stream));
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_stage[1], blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    slam_size_walk_lds(ctx, pyr, jobs, njobs);
     rc = slam_hip_track_batch_d(ctx, pyr, (const slam_track_job*)ctx->d_stage[0], njobs,
                                 (const uint8_t*)ctx->d_stage[1], blob_bytes, (slam_track_result*)ctx->d_stage[2]);
     if (rc != SLAM_HIP_OK) return rc;

@@ -112,7 +112,7 @@ __device__ __forceinline__ LeanSlices lean_pick_slices(int nunits, int nA, int n
 
 // LDS bytes a level needs (INT_MAX: a shape this path does not take), with the window's column phase x0 & 3 at its
 // worst, so that the answer depends on sizes only and a walk can be turned away before its first level is searched.
-__device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized) {
+__host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized) {
     const int G = (tw + 3) >> 2, NG = th * G;
     const bool strips = step == 1;
     const int cols = (aw + 6) >> 2;
@@ -124,7 +124,7 @@ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int ste
     const int raw_bytes = NG * 8 + (resized ? (G * 4 + th) * 8 : 0);
     // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
     if (tw > 256 || th > 256 || tw * th > 66051 || tp > 64 || nx * ny > 4096) return INT_MAX;
-    return ((nacc * 8 + 15) & ~15) + cap * 8 + ((cap * 4 + 15) & ~15) + max(tile_bytes, raw_bytes);
+    return ((nacc * 8 + 15) & ~15) + cap * 8 + ((cap * 4 + 15) & ~15) + (tile_bytes > raw_bytes ? tile_bytes : raw_bytes);
 }
 
 // accumulator index of the cell in tile column c (= o + x), row y, of a stride-1 search: strips of 4 columns run down

@@ -234,6 +234,7 @@ extern "C" int slam_hip_project_track_batch(slam_ctx* ctx, const slam_pyr* pyr, 
     rc = slam_hip_warp_batch_d(ctx, (const uint8_t*)ctx->d_stage[1], desc_bytes, (const slam_warp_job*)t0, njobs,
                                (uint8_t*)ctx->d_stage[2], out_bytes, (int32_t*)(t0 + o_s), max_pix);
     if (rc != SLAM_HIP_OK) return rc;
+    slam_size_walk_lds(ctx, pyr, tj.data(), njobs);
     rc = slam_hip_track_batch_d(ctx, pyr, (const slam_track_job*)(t0 + o_t), njobs, (const uint8_t*)ctx->d_stage[2],
                                 out_bytes ? out_bytes : 1, (slam_track_result*)(t0 + o_r));
     if (rc != SLAM_HIP_OK) return rc;
@@ -530,6 +531,7 @@ extern "C" int slam_hip_track_ellipse_batch(slam_ctx* ctx, const slam_pyr* pyr, 
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(dblob, blob, blob_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = slam_hip_ellipse_masks_d(ctx, (const slam_ellipse_job*)(t0 + o_e), njobs, dblob, off, nullptr, max_pix);
     if (rc != SLAM_HIP_OK) return rc;
+    slam_size_walk_lds(ctx, pyr, tj.data(), njobs);
     rc = slam_hip_track_batch_d(ctx, pyr, (const slam_track_job*)t0, njobs, dblob, off, (slam_track_result*)(t0 + o_r));
     if (rc != SLAM_HIP_OK) return rc;
     SLAM_HIP_CHECK(ctx, hipMemcpyAsync(out, t0 + o_r, rb, hipMemcpyDeviceToHost, ctx->stream));

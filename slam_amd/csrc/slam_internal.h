@@ -23,6 +23,8 @@ struct slam_ctx {
     int match_lds_bytes = 9 * 1024;    // LDS per search job: 16 jobs share a CU's 160 KB, as many as its registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
     int force_direct = 0;   // SLAM_HIP_FORCE_DIRECT=1: search by direct evaluation (cross-check of the tiled core)
     int lean_lds_bytes = 8192;         // LDS per job of the lean walk kernel: 20 jobs per CU
+    int lean_lds_user = 0;             // set by the caller (slam_hip_set_walk_lds, SLAM_HIP_WALK_LDS_KB): never sized automatically
+    int lean_lds_once = 0;             // budget of the next walk launch only (slam_size_walk_lds), 0 = lean_lds_bytes
     int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: walks and searches skip the lean kernels (cross-check of them)
     int lean_match_lds_bytes = 10240;  // LDS per job of the lean single-search kernel (SLAM_HIP_SEARCH_LDS_KB)
     int lean_match_min_jobs = 64;      // smaller batches of single searches take the general kernel alone (SLAM_HIP_SEARCH_LEAN_MIN)
@@ -97,6 +99,7 @@ int slam_queue_reserve(slam_ctx* ctx, int njobs);
 int slam_upload_image(slam_ctx* ctx, uint8_t* d_dst, size_t dpitch, const uint8_t* h_src, size_t spitch, size_t width, size_t rows,
                       size_t slot_off);
 int slam_track_scratch_init(slam_ctx* ctx);
+void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs);
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
                       size_t blob_bytes, slam_track_result* d_out, int* queue);
 

@@ -738,6 +738,9 @@ def test_c3_track_walk_with_ellipse_windows(ctx, oracle):
     pyr = api.ImagePyramid(ctx, f1, subs)
     try:
         got = api.track_batch(ctx, pyr, jobs)
+        # the entry point saw the shapes on the host and sized the lean walk kernel for them: only walks that leave
+        # the image, are cropped by it or find nothing to visit are left to the general kernel (all of them without sizing)
+        assert api.debug_walk_deferred(ctx) <= len(jobs) // 4
     finally:
         pyr.close()
     levels = oracle.pyramid(f1, subs)
