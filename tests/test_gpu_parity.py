@@ -487,6 +487,25 @@ def test_fast_matches_oracle(ctx, oracle, w, h):
             assert _kp_set(got[f]) == _kp_set(ref), (w, h, thr, nms, f)   # same set AND same (row-major) order
 
 
+@pytest.mark.parametrize("nframes", [8, 11, 16, 21])
+def test_fast_batches_of_eight_frames_and_more(ctx, oracle, nframes):
+    """From 8 frames on a launch deals whole frames to the XCDs (one-dimensional grid, the last round of 8 part
+    empty when the count is no multiple of 8): every frame's list against the oracle, across tile seams, with and
+    without suppression, dense and sparse."""
+    rng = np.random.default_rng(977 + nframes + SOAK_SEED)
+    w, h = 300 + nframes, 70 + nframes
+    frames = np.stack([synth.frame(w, h, 400 + i, (5 * i, 3 * i)) for i in range(nframes)])
+    frames[1] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    frames[-1] = (rng.integers(0, 256, (h, w), dtype=np.uint8) >> 5 << 5)
+    for thr, nms in [(12, True), (60, True), (25, False)]:
+        got, counts, rc = api.fast(ctx, frames, thr, nms)
+        assert rc == 0
+        for f in range(nframes):
+            ref = oracle.fast(frames[f], thr, nms)
+            assert counts[f] == len(ref), (nframes, thr, nms, f)
+            assert _kp_set(got[f]) == _kp_set(ref), (nframes, thr, nms, f)
+
+
 def test_fast_random_images_against_oracle(ctx, oracle):
     """Differential test of FAST + NMS over random sizes (down to the 7x7 minimum, across the 248-column and 30-row
     tile seams), thresholds, both NMS settings and textures that stress ties: flat areas, steps, coarse noise with
