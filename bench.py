@@ -78,6 +78,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle: no parity gates, no cpu_baseline")
     ap.add_argument("--no-side", action="store_true", help="skip the extra legs (C1, C3, line walk, FAST)")
     ap.add_argument("--no-fast", action="store_true", help="skip the FAST (C4) leg")
+    ap.add_argument("--no-fast-sparse", action="store_true",
+                    help="FAST leg at threshold 10 only (profiling: keeps one kind of launch per kernel name)")
     ap.add_argument("--cpu-procs", type=int, default=16,
                     help="worker processes of the additional all-cores CPU figure (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -301,10 +303,14 @@ def fast_leg(api, capi, ctx, stream, dev, args, traffic):
     # the same frames at a threshold that keeps a few thousand corners per frame - the regime getSortedKeyPoints steers
     # fastThreshold into (new_point.cpp:113-127); threshold 10 on this texture is dominated by noise corners
     sparse_thr = 40
-    go(sparse_thr)
-    torch.cuda.synchronize()
-    sparse_cnt = float(d_cnt.cpu().numpy().mean())
-    sparse_ms = timed(stream, lambda: go(sparse_thr), max(5, args.steps))
+    sparse = None
+    if not args.no_fast_sparse:
+        go(sparse_thr)
+        torch.cuda.synchronize()
+        sparse_cnt = float(d_cnt.cpu().numpy().mean())
+        sparse_ms = timed(stream, lambda: go(sparse_thr), max(5, args.steps))
+        sparse = {"threshold": sparse_thr, "ms": sparse_ms, "value": w * h * nfr / (sparse_ms * 1e-3), "unit": "px/s",
+                  "corners_per_frame": sparse_cnt}
     go()
     torch.cuda.synchronize()
     cnt = d_cnt.cpu().numpy()
@@ -325,8 +331,7 @@ def fast_leg(api, capi, ctx, stream, dev, args, traffic):
             "roofline": {"bound": "hbm", "kernel": "fast_tile_kernel+fast_scan_kernel+fast_scatter_kernel", "achieved": alg / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": tr, "algorithmic_bytes_per_launch": alg},
-            "sparse": {"threshold": sparse_thr, "ms": sparse_ms, "value": w * h * nfr / (sparse_ms * 1e-3), "unit": "px/s",
-                       "corners_per_frame": sparse_cnt},
+            "sparse": sparse,
             "parity": parity}
 
 

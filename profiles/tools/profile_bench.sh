@@ -9,8 +9,8 @@ TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --no-cpu"
-BENCH_PMC="python3 $PWD/bench.py --steps 3 --warmup 1 --no-cpu"
+BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --no-cpu --no-fast-sparse"
+BENCH_PMC="python3 $PWD/bench.py --steps 3 --warmup 1 --no-cpu --no-fast-sparse"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 echo "stats pass done"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $BENCH_PMC > $OUT/fetch.log 2>&1

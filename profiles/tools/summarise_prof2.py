@@ -49,14 +49,14 @@ def main():
     prof = os.path.join(ROOT, "profiles")
     text, avg = kernel_stats(sqlite3.connect(os.path.join(src, "stats", "stats_results.db")))
     with open(os.path.join(prof, tag + "_kernel_stats.txt"), "w") as fh:
-        fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu   (1 GPU, %d sequences per step)\n" % nseq)
+        fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-fast-sparse   (1 GPU, %d sequences per step)\n" % nseq)
         fh.write(text + "\n")
     print(text)
     fetch = counter_by_kernel(os.path.join(src, "fetch", "fetch_results.db"), "FETCH_SIZE")
     write = counter_by_kernel(os.path.join(src, "write", "write_results.db"), "WRITE_SIZE")
     cf = counter_by_kernel(os.path.join(src, "calib_fetch", "calib_results.db"), "FETCH_SIZE")
     cw = counter_by_kernel(os.path.join(src, "calib_write", "calib_results.db"), "WRITE_SIZE")
-    lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu",
+    lines = ["rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-fast-sparse",
              "counter values are KB per launch (mean over launches); read bytes = FETCH_SIZE x 1024 x correction", ""]
     lines.append("calibration (profiles/tools/pmc_calib.hip; each read kernel reads %d bytes once):" % CALIB_BYTES)
     factor = {}
