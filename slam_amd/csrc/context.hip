@@ -212,6 +212,8 @@ int slam_queue_reserve(slam_ctx* ctx, int njobs) {
         return slam_set_error(ctx, SLAM_HIP_ENOMEM, "walk queue hipMalloc(%zu words): %s", want + 16, hipGetErrorString(e));
     }
     ctx->queue_jobs = want;
+    ctx->queue_cnt = 0; ctx->queue_last = 0;
+    SLAM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 16 * sizeof(int), ctx->stream));     // both counters start at zero
     return SLAM_HIP_OK;
 }
 

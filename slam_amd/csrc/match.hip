@@ -231,7 +231,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
                                                         unsigned long long blob_bytes, float* scores,
                                                         unsigned long long scores_len,
                                                         slam_match_result* __restrict__ out, int force_direct, int lds_total,
-                                                        const int* __restrict__ queue) {
+                                                        int* __restrict__ queue, int cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     const LdsPlan plan = make_lds_plan(lds_total);
@@ -240,7 +240,10 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
         if (j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
         return;
     }
-    const int count = min(queue[0], njobs);
+    // The queue has two counters, used by alternate launches: this launch reads word `cnt` and clears the other one
+    // for the lean kernel of the next launch (which starts after this kernel has ended), so no launch needs a memset.
+    if (blockIdx.x == 0 && threadIdx.x == 0) queue[cnt ^ 8] = 0;
+    const int count = min(queue[cnt], njobs);
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const int j = queue[SLAM_DEFER_LIST + q];
         __syncthreads();                                   // the previous job's last readers of the dynamic LDS
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_lean_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes, const float* scores,
-                                                        slam_match_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
+                                                        slam_match_result* __restrict__ out, int lds_total, int* __restrict__ queue, int cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     const int j = blockIdx.x;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_lean_kernel(sla
     }
     if (threadIdx.x == 0) {
         if (o.ok) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
-        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
+        else queue[SLAM_DEFER_LIST + atomicAdd(queue + cnt, 1)] = j;
     }
 }
 
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
                                                         slam_track_result* __restrict__ out, int force_direct, int lds_total,
-                                                        const int* __restrict__ queue) {
+                                                        int* __restrict__ queue, int cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ TrackLevel lc[SLAM_HIP_MAX_LEVELS];
     lds_u8* lds = (lds_u8*)dyn_lds;
@@ -446,7 +449,8 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
         return;
     }
-    const int count = min(queue[0], njobs);
+    if (blockIdx.x == 0 && threadIdx.x == 0) queue[cnt ^ 8] = 0;      // the other counter, for the next launch (see match_kernel)
+    const int count = min(queue[cnt], njobs);
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const int j = queue[SLAM_DEFER_LIST + q];
         __syncthreads();                                   // the previous job's last readers of lc and the dynamic LDS
@@ -570,7 +574,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
-                                                        slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
+                                                        slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue, int cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own.  Workgroup b takes job
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(sla
     const bool done = lean_walk(pyr, job, blob, blob_bytes, lds, lds_total, r);
     if (threadIdx.x == 0) {
         if (done) out[j] = r;
-        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
+        else queue[SLAM_DEFER_LIST + atomicAdd(queue + cnt, 1)] = j;
     }
 }
 
@@ -746,22 +750,24 @@ extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (ctx->force_direct || ctx->no_lean || njobs < ctx->lean_match_min_jobs) {
         hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
                            pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
-                           (unsigned long long)scores_len, d_out, ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
+                           (unsigned long long)scores_len, d_out, ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr, 0);
         SLAM_HIP_CHECK(ctx, hipGetLastError());
         return SLAM_HIP_OK;
     }
     rc = slam_queue_reserve(ctx, njobs);
     if (rc != SLAM_HIP_OK) return rc;
     int* queue = ctx->d_queue;
-    SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
+    const int cnt = ctx->queue_cnt;                        // this launch's counter; the general kernel clears the other one
+    ctx->queue_cnt ^= 8;
+    ctx->queue_last = cnt;
     hipLaunchKernelGGL(match_lean_kernel, dim3(njobs), dim3(SLAM_WG), ctx->lean_match_lds_bytes, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, (const float*)d_scores, d_out,
-                       ctx->lean_match_lds_bytes, queue);
+                       ctx->lean_match_lds_bytes, queue, cnt);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     const int grid = njobs < 4096 ? njobs : 4096;
     hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
-                       (unsigned long long)scores_len, d_out, 0, ctx->match_lds_bytes, (const int*)queue);
+                       (unsigned long long)scores_len, d_out, 0, ctx->match_lds_bytes, queue, cnt);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }
@@ -869,13 +875,16 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
         ctx->lean_lds_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                           ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
+                           ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr, 0);
         SLAM_HIP_CHECK(ctx, hipGetLastError());
         return SLAM_HIP_OK;
     }
     int rc2 = slam_queue_reserve(ctx, njobs);
     if (rc2 != SLAM_HIP_OK) return rc2;
-    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, ctx->d_queue);
+    const int cnt = ctx->queue_cnt;                        // this launch's counter; the general kernel clears the other one
+    ctx->queue_cnt ^= 8;
+    ctx->queue_last = cnt;
+    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, ctx->d_queue, cnt);
 }
 
 // The entry points that take their job table from the host see the shapes before the launch: they size the lean walk
@@ -915,18 +924,22 @@ void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job
 // Lean kernel over all jobs, then the general kernel over whatever it queued.  `queue`: device words, SLAM_DEFER_LIST
 // + njobs of them.  Allocates nothing.
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
-                      size_t blob_bytes, slam_track_result* d_out, int* queue) {
+                      size_t blob_bytes, slam_track_result* d_out, int* queue, int cnt) {
     const int lds = ctx->lean_lds_once ? ctx->lean_lds_once : ctx->lean_lds_bytes;      // a host-table entry point may have sized this launch
     ctx->lean_lds_once = 0;
-    SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
+    // cnt < 0: a queue shared by every context of the device (the no-alloc entry point): cleared here, counter 0
+    if (cnt < 0) {
+        SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
+        cnt = 0;
+    }
     hipLaunchKernelGGL(track_lean_kernel, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), lds, ctx->stream, pyr->dev, d_jobs, njobs,
-                       d_blob, (unsigned long long)blob_bytes, d_out, lds, queue);
+                       d_blob, (unsigned long long)blob_bytes, d_out, lds, queue, cnt);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     // enough workgroups to fill the chip if everything was queued, few enough to start and end in microseconds if nothing was
     const int grid = njobs < 4096 ? njobs : 4096;
     hipLaunchKernelGGL(track_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                       0, ctx->match_lds_bytes, (const int*)queue);
+                       0, ctx->match_lds_bytes, queue, cnt);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }
@@ -949,11 +962,12 @@ extern "C" int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr
         ctx->lean_lds_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                           ctx->force_direct, ctx->match_lds_bytes, (const int*)nullptr);
+                           ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr, 0);
         SLAM_HIP_CHECK(ctx, hipGetLastError());
         return SLAM_HIP_OK;
     }
-    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, q);
+    ctx->queue_last = -1;
+    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, q, -1);
 }
 
 extern "C" int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs,
@@ -1034,8 +1048,12 @@ extern "C" int slam_hip_debug_walk_deferred(slam_ctx* ctx, int* out_deferred) {
     *out_deferred = 0;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ctx->d_queue || ctx->force_direct || ctx->no_lean) return SLAM_HIP_OK;
-    SLAM_HIP_CHECK(ctx, hipMemcpy(out_deferred, ctx->d_queue, sizeof(int), hipMemcpyDeviceToHost));
+    if (ctx->force_direct || ctx->no_lean) return SLAM_HIP_OK;
+    const int* counter = nullptr;                           // of the context's last launch with a queue
+    if (ctx->queue_last >= 0) counter = ctx->d_queue ? ctx->d_queue + ctx->queue_last : nullptr;
+    else if (ctx->device >= 0 && ctx->device < SLAM_MAX_DEVICES) counter = g_walk_scratch_ptr[ctx->device];
+    if (!counter) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipMemcpy(out_deferred, counter, sizeof(int), hipMemcpyDeviceToHost));
     return SLAM_HIP_OK;
 }
 
