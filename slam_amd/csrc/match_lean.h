@@ -284,6 +284,9 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     __syncthreads();                                       // the previous level's readers of this LDS are done
 
     // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
+    // A template of at most 32 groups (the coarse levels of a walk) is not sorted into the two lists: compacting it
+    // costs more instructions than masking every group of so short a list does.
+    const bool tiny = NG <= 32;
     unsigned sp_part = 0;
     int nA = 0, nB = 0;
     const float rG = __builtin_amdgcn_rcpf((float)G);
@@ -342,13 +345,15 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             }
         }
         __syncthreads();
-        for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
-            const int i = i0 + lane;
-            const unsigned M = i < NG ? (unsigned)(raw[i] >> 32) : 0u;
-            nA += __builtin_popcountll(__ballot(M == 0xFFFFFFFFu));
-            nB += __builtin_popcountll(__ballot(M != 0u && M != 0xFFFFFFFFu));
-        }
+        if (!tiny)
+            for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+                const int i = i0 + lane;
+                const unsigned M = i < NG ? (unsigned)(raw[i] >> 32) : 0u;
+                nA += __builtin_popcountll(__ballot(M == 0xFFFFFFFFu));
+                nB += __builtin_popcountll(__ballot(M != 0u && M != 0xFFFFFFFFu));
+            }
     }
+    if (tiny) { nA = 0; nB = NG; }
     const unsigned spfull = wave_sum_u32(sp_part);
     const Norms nm = make_norms(spfull);
     STAMP(51);
@@ -358,7 +363,15 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int S = lsl.S, na = lsl.na, nA1 = na * S;           // all-kept entries per slice; the rest of them joins the masked part
     const int nb = lsl.nb, nB1 = nb * S;
     __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
-    {
+    if (tiny) {                                             // every group a masked entry, in template order
+        if (lane < NG) {
+            const unsigned long long r = raw[lane];
+            const int u = (int)(((float)lane + 0.5f) * rG), gq = lane - u * G;
+            list[lane] = ((unsigned long long)((unsigned)(u * tp + gq) * 8u) << 32) | (unsigned)r;
+            marr[lane] = (unsigned)(r >> 32);
+        }
+        for (int p = NG + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p] = 0u; }
+    } else {
         int baseA = 0, baseB = nA;
         for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
             const int i = i0 + lane;
