@@ -137,7 +137,7 @@ def level_cells_and_bytes(tsize=TSIZE, subs=SUBS, stride=STRIDE):
 def build_time_steps(nseq, nsteps, seed, rng):
     """nseq independent sequences, nsteps time-steps of each.  Returns (frames[nsteps, nseq, H, W] u8, jobs: one
     structured array per time-step (frame = sequence index within the time-step), blob u8, truth[nsteps][nseq*NFEAT, 2]).
-    A sequence is a window sliding over its own procedural canvas: the frame at time t is frame 0 translated by an
+    A sequence is a window sliding over its own procedural canvas (band-limited value noise, synth.canvas_smooth): the frame at time t is frame 0 translated by an
     integer (u, v), |u|, |v| <= 6; templates are cut from frame 0 with warped-quad-like masks (cut corners); the
     prediction handed to the search is the truth plus an error of up to 3.9 pixels per axis."""
     from slam_amd import synth
@@ -149,7 +149,7 @@ def build_time_steps(nseq, nsteps, seed, rng):
     margin = TSIZE + 30
     pad = 8
     for s in range(nseq):
-        big = synth.canvas(-pad, -pad, W + 2 * pad, H + 2 * pad, seed + s)
+        big = synth.canvas_smooth(-pad, -pad, W + 2 * pad, H + 2 * pad, seed + s)
         f0 = big[pad:pad + H, pad:pad + W]
         pts = np.array(synth.feature_grid(W, H, NFEAT, margin, rng), np.int64)
         offs = np.zeros((NFEAT, 2), np.int64)

@@ -34,6 +34,26 @@ def canvas(x0, y0, w, h, seed, cell=16):
     return np.clip(v, 0, 255).astype(np.uint8)
 
 
+def canvas_smooth(x0, y0, w, h, seed, cell=32):
+    """u8 texture at canvas coordinates like `canvas`, but band-limited the way camera images are: value noise (random
+    intensities on a `cell`-pixel grid, bilinearly interpolated, integer arithmetic) plus a weaker octave at half the
+    cell and a little per-pixel noise.  A pyramid level subsampled by 4 still shows the structure, so a coarse lattice
+    search lands next to the truth."""
+    X = (np.arange(w, dtype=np.int64) + x0 + (1 << 20))[None, :] + np.zeros((h, 1), np.int64)
+    Y = (np.arange(h, dtype=np.int64) + y0 + (1 << 20))[:, None] + np.zeros((1, w), np.int64)
+
+    def octave(c, amp, salt):
+        gx, gy, fx, fy = X // c, Y // c, X % c, Y % c
+        v = lambda dx, dy: (hash32(gx + dx, gy + dy, seed ^ salt) % np.uint32(amp)).astype(np.int64)
+        top = v(0, 0) * (c - fx) + v(1, 0) * fx
+        bot = v(0, 1) * (c - fx) + v(1, 1) * fx
+        return (top * (c - fy) + bot * fy) // (c * c)
+
+    noise = (hash32(X, Y, seed) % np.uint32(3)).astype(np.int64)
+    v = 10 + octave(cell, 200, 0x1234567) + octave(max(cell // 2, 2), 30, 0x89ABCDE) + noise
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
 def frame(w, h, seed, shift=(0, 0)):
     return canvas(shift[0], shift[1], w, h, seed)
 
