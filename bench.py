@@ -69,12 +69,15 @@ LINE_JOB_DT = np.dtype([("desc_off", "<i8"), ("amask_off", "<i8"), ("frame", "<i
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sequences-per-gpu", type=int, default=512,
                     help="independent sequences a GPU owns; a step processes one frame of each (C5: 512 x 8 GPUs)")
     ap.add_argument("--time-steps", type=int, default=4, help="time-steps of every sequence resident in HBM; steps cycle through them")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="repeat the CPU sample until this much CPU time")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="build each time-step's pyramid on the walk's own stream, right before its walk (default: the pyramid "
+                         "of time-step k+1 is built on a second stream while time-step k is walked; two pyramids, double-buffered)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle: no parity gates, no cpu_baseline")
     ap.add_argument("--no-side", action="store_true", help="skip the extra legs (C1, C3, line walk, FAST)")
     ap.add_argument("--no-fast", action="store_true", help="skip the FAST (C4) leg")
@@ -629,26 +632,63 @@ def main(argv=None):
     d_jobs = [torch.from_numpy(j.view(np.uint8).reshape(-1)).to(dev) for j in jobs]
     d_blob = torch.from_numpy(blob).to(dev)
     d_out = [torch.zeros(njobs * TRACK_RES_DT.itemsize, dtype=torch.uint8, device=dev) for _ in range(nts)]
-    stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by the kernels and the events
+    stream = torch.cuda.Stream(device=dev)      # a real (non-null) stream shared by the walk kernels and the events
     torch.cuda.set_stream(stream)
     ctx = api.Context(local_rank, stream=stream.cuda_stream)
     fbytes = nseq * W * H
-    pyr = api.ImagePyramid(ctx, None, SUBS, device_ptr=d_frames.data_ptr(), pitch=W, frame_stride=W * H, shape=(nseq, H, W))
     L = capi.lib()
     h_frames = torch.from_numpy(frames).pin_memory() if args.with_h2d else None
+    # The pyramid build is HBM-bound and the walk VALU-bound: with the pyramid of time-step k+1 built on a second stream
+    # while time-step k is walked they share the chip.  Two pyramids, written and read in turn; events order the streams.
+    overlap = not args.no_overlap and not args.with_h2d
+    mk_pyr = lambda c: api.ImagePyramid(c, None, SUBS, device_ptr=d_frames.data_ptr(), pitch=W, frame_stride=W * H, shape=(nseq, H, W))
+    if overlap:
+        stream_b = torch.cuda.Stream(device=dev)
+        ctx_b = api.Context(local_rank, stream=stream_b.cuda_stream)
+        pyrs = [mk_pyr(ctx_b), mk_pyr(ctx_b)]
+        built = [torch.cuda.Event(), torch.cuda.Event()]
+        walked = [torch.cuda.Event(), torch.cuda.Event()]
+    else:
+        stream_b, ctx_b = stream, ctx
+        pyrs = [mk_pyr(ctx)]
+    pyr = pyrs[0]
+    issued = {"for": -1}                        # the step whose pyramid has been put on the second stream already
+
+    def build(k):
+        p, t = k & 1, k % nts
+        stream_b.wait_event(walked[p])          # the walk that last read this pyramid (no-op before the first one)
+        pyrs[p].rebuild_d(d_frames.data_ptr() + t * fbytes, W, W * H)
+        built[p].record(stream_b)
+        issued["for"] = k
+
+    def walk(k, p):
+        t = k % nts
+        capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyrs[p].handle, C.c_void_p(d_jobs[t].data_ptr()), njobs,
+                                                        C.c_void_p(d_blob.data_ptr()), blob.size,
+                                                        C.c_void_p(d_out[t].data_ptr())))
 
     def step(k, ev=None):
+        """One time-step: pyramid of frame k % nts of every sequence + the walk of all their features.  ev: a pair of
+        timing events put around the walk kernels on their stream."""
+        if overlap:
+            if issued["for"] != k:
+                build(k)
+            stream.wait_event(built[k & 1])
+            if ev is not None:
+                ev[0].record(stream)
+            walk(k, k & 1)
+            if ev is not None:
+                ev[1].record(stream)
+            walked[k & 1].record(stream)
+            build(k + 1)
+            return
         t = k % nts
         if h_frames is not None:
             d_frames[t].copy_(h_frames[t], non_blocking=True)
-        if ev is not None:
-            ev[2].record(stream)
         pyr.rebuild_d(d_frames.data_ptr() + t * fbytes, W, W * H)
         if ev is not None:
             ev[0].record(stream)
-        capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, C.c_void_p(d_jobs[t].data_ptr()), njobs,
-                                                        C.c_void_p(d_blob.data_ptr()), blob.size,
-                                                        C.c_void_p(d_out[t].data_ptr())))
+        walk(k, 0)
         if ev is not None:
             ev[1].record(stream)
 
@@ -703,22 +743,32 @@ def main(argv=None):
     # ---- timing --------------------------------------------------------------------------------
     for k in range(args.warmup):
         step(k)
-    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    # timing events around the walk kernels of every eighth step: an event pair costs the stream about as much as a
+    # small kernel, and the kernels' mean duration does not need every launch
+    evs = {k: tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for k in range(0, args.steps, 8)}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + k, evs[k])
+        step(args.warmup + k, evs.get(k))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    pyr_ms = float(np.mean([e[2].elapsed_time(e[0]) for e in evs]))
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs.values()]))
+    # the pyramid build alone, outside the timed steps (inside them it runs beside the walk)
+    pev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) for _ in range(10)]
+    for k, (a, b) in enumerate(pev):
+        a.record(stream_b)
+        pyrs[0].rebuild_d(d_frames.data_ptr() + (k % nts) * fbytes, W, W * H)
+        b.record(stream_b)
+    torch.cuda.synchronize()
+    issued["for"] = -1
+    pyr_ms = float(np.mean([a.elapsed_time(b) for a, b in pev]))
     pyr_bytes = nseq * (W * H + sum(pyr.level(i).w * pyr.level(i).h for i in range(1, len(SUBS))))
     tot_pos = float(sum(positions[(args.warmup + k) % nts] for k in range(args.steps)))
     elapsed, tot_pos = parallel.reduce_max_sum(elapsed, tot_pos, rdev)
@@ -751,6 +801,7 @@ def main(argv=None):
                        "sequences_per_gpu": nseq, "sequences": nseq * world, "features_per_frame": NFEAT,
                        "positions_per_step_per_gpu": float(np.mean(positions)),
                        "frames_per_s": nseq * world * args.steps / elapsed, "tracked_fraction": tracked, "h2d_in_step": bool(args.with_h2d),
+                       "pyramid_overlapped": bool(overlap),
                        "parity": None if args.no_cpu else "every rank compared a sample of each time-step's results with the oracle bit for bit",
                        "parallelism": "sequences sharded over %d GPU(s), no collective on the data path" % world},
             "roofline": {"bound": "hbm", "kernel": "track_lean_kernel+track_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -773,7 +824,10 @@ def main(argv=None):
         }
         line.update(side)
         print(json.dumps(line))
-    pyr.close()
+    for p in pyrs:
+        p.close()
+    if overlap:
+        ctx_b.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
