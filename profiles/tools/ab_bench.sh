@@ -1,5 +1,10 @@
+#!/bin/bash
+# Same-box A/B of two builds of the library on the bench's walk, C1 and C3 legs, alternating twice (boxes differ by a
+# few per cent, so a comparison across gpurun calls says little).
+# usage: profiles/tools/ab_bench.sh <libA.so> <libB.so>       (paths relative to the repository root)
+A=${1:-slam_amd/lib/diag/libslam_hip_prev.so}; B=${2:-slam_amd/lib/libslam_hip.so}
 for i in 1 2; do
-for lib in slam_amd/lib/diag/libslam_hip_prev.so slam_amd/lib/libslam_hip.so; do
+for lib in $A $B; do
 SLAM_HIP_LIB=$PWD/$lib timeout -k 10 300 python3 bench.py --no-cpu --no-fast 2>&1 | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
