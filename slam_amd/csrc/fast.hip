@@ -4,16 +4,17 @@
 // Kernel 1 (fast_tile_kernel): one workgroup (4 wavefronts) per tile of 248 x 30 output pixels of one
 //   frame.  The tile's pixels (+ 4-pixel halo) are staged into LDS once.
 //   Phase 1: each lane tests 4 adjacent pixels with the opposite-pair test (a 9-long arc contains one
-//   pixel of every opposite ring pair, so "all 8 pairs have a brighter / darker member" is necessary)
-//   and the wavefront compacts the candidates of 4 score rows at a time into a list.
-//   Phase 2: one lane per listed candidate computes the exact score; the stored score (score for
-//   corners, 0 otherwise) of tile rows -1..30 and columns -4..251 goes into an LDS score tile.
-//   Phase 3: each wavefront walks its output rows, applies the strict 3x3 non-max test and compacts the
-//   survivors of a row with ballots into that (row, tile) segment of the frame's key table; the
-//   segment's length goes into a count table.  No atomics: every segment has a fixed place.
+//   pixel of every opposite ring pair, so "all 8 pairs have a brighter / darker member" is necessary),
+//   8 pixel rows per wavefront on shared window rows, the even pairs first and the odd ones only on
+//   dense rows; the candidates of the 8 rows are listed with one wave scan.
+//   Phase 2: each lane scores two listed candidates at once (exact, threshold-free); the stored score
+//   (score for corners, 0 otherwise) of tile rows -1..30 and columns -4..251 goes into an LDS score tile.
+//   Phase 3: each wavefront applies the strict 3x3 non-max test to its output rows; the tile's survivors
+//   are written in row-major order into the tile's area of the frame's key table, the rows' counts
+//   into a count table.  No atomics: every tile has a fixed place.
 // Kernel 2 (fast_scan_kernel): one workgroup per frame turns the (row, tile) counts into offsets in
 //   row-major order - cv::FAST's keypoint order - and reports the frame's total.
-// Kernel 3 (fast_scatter_kernel): copies every segment to its place in the output as keypoints.
+// Kernel 3 (fast_scatter_kernel): writes every tile's keys to their places in the output as keypoints.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -75,12 +76,6 @@ __device__ __forceinline__ FastTile fast_tile_of_block(int ntx, int nty, int nfr
 typedef __attribute__((address_space(3))) unsigned char fl_u8;
 typedef __attribute__((address_space(3))) unsigned short fl_u16;
 typedef __attribute__((address_space(3))) unsigned fl_u32;
-
-// byte i (0..11) of the 12-byte window {a, b, c}
-__device__ __forceinline__ int win_byte(unsigned a, unsigned b, unsigned c, int i) {
-    const unsigned wd = i < 4 ? a : (i < 8 ? b : c);
-    return (int)((wd >> (8 * (i & 3))) & 0xffu);
-}
 
 // (dx, dy) of ring position k of cv::FAST's 16-pixel circle
 __device__ __forceinline__ constexpr int ring_dx(int k) {
@@ -166,41 +161,11 @@ __device__ __forceinline__ fast_s2 fast_arc_scores2(const fl_u8* p1, const fl_u8
     return fast_s2{(short)((int)(best & 0xffffu) - 256), (short)((int)(best >> 16) - 256)};
 }
 
-// Opposite-pair test of a lane's 4 adjacent pixels (the window rows dy = -3..3 are A/B/Cw[0..6]: dwords at pixel bytes
-// 4*lane, +4, +8).  Two pixels per operation: pixels j = 0 and 2 as 16-bit halves, then pixels 1 and 3.  A 9-long arc holds
-// a member of every opposite ring pair, so for a bright arc every pair has a member brighter than v+t (min over pairs of
-// the pair maximum > v+t), for a dark arc every pair has a member darker than v-t (max over pairs of the pair minimum < v-t).
-__device__ __forceinline__ void fast_pair_test(const unsigned* A, const unsigned* B, const unsigned* Cw, int t, unsigned& candB, unsigned& candD) {
-    fast_u2 mn_of_mx[2], mx_of_mn[2];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-#pragma unroll
-        for (int o = 0; o < 2; o++) {
-            const fast_u2 r0 = ring_pair(A[3 + ring_dy(k)], B[3 + ring_dy(k)], Cw[3 + ring_dy(k)], ring_dx(k), o);
-            const fast_u2 r1 = ring_pair(A[3 + ring_dy(k + 8)], B[3 + ring_dy(k + 8)], Cw[3 + ring_dy(k + 8)], ring_dx(k + 8), o);
-            const fast_u2 mx = __builtin_elementwise_max(r0, r1), mn = __builtin_elementwise_min(r0, r1);
-            mn_of_mx[o] = k == 0 ? mx : __builtin_elementwise_min(mn_of_mx[o], mx);
-            mx_of_mn[o] = k == 0 ? mn : __builtin_elementwise_max(mx_of_mn[o], mn);
-        }
-    }
-    const fast_u2 T = fast_u2{(unsigned short)t, (unsigned short)t};
-    const fast_u2 one = fast_u2{(unsigned short)1, (unsigned short)1};
-    unsigned nb[2], nd[2];                               // 0 / 1 per 16-bit half: pixel (o, o + 2) is a bright / dark candidate
-#pragma unroll
-    for (int o = 0; o < 2; o++) {
-        const fast_u2 v = ring_pair(A[3], B[3], Cw[3], 0, o);
-        // saturating differences are non-zero exactly when the comparison holds
-        nb[o] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_sub_sat(mn_of_mx[o], v + T), one));
-        nd[o] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_sub_sat(v, mx_of_mn[o] + T), one));
-    }
-    // halves (pixel 0 | pixel 1 << 1, pixel 2 | pixel 3 << 1) -> bits 0..3
-    const unsigned pb = nb[0] | (nb[1] << 1), pd = nd[0] | (nd[1] << 1);
-    candB = (pb & 3u) | ((pb >> 14) & 12u);
-    candD = (pd & 3u) | ((pd >> 14) & 12u);
-}
-
-// The same test on precomputed shifted pairs: S[d][s + 3] holds bytes (4 + s, 6 + s) of window row d (s = -3..4) as
-// 16-bit halves, i.e. ring_pair(.., dx, o) with s = dx + o.  A window row's shifted pairs are shared by the pixel rows
+// Opposite-pair test of a lane's 4 adjacent pixels, two pixels per operation (pixels j = 0 and 2 as 16-bit halves, then
+// pixels 1 and 3).  A 9-long arc holds a member of every opposite ring pair, so for a bright arc every pair has a member
+// brighter than v+t (min over pairs of the pair maximum > v+t), for a dark arc every pair has a member darker than v-t
+// (max over pairs of the pair minimum < v-t).  The test runs on precomputed shifted pairs: S[d][s + 3] holds bytes
+// (4 + s, 6 + s) of window row d (s = -3..4) as 16-bit halves, i.e. ring_pair(.., dx, o) with s = dx + o.  A window row's shifted pairs are shared by the pixel rows
 // and ring positions that meet on it (dy = -1, 0, +1 use the same four, dy = +-3 and dy = +-2 overlap in two), so the
 // 8 rows of a wavefront need about 100 byte picks instead of 272.  `q`: the pixel row, whose window rows are q .. q + 6.
 template <int Q>
