@@ -501,21 +501,13 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             for (int q = 0; q < NQ; q++)
                 if (q * SLAM_WG < ncell && est[q] != -FLT_MAX && est[q] >= keep_from) best_update(b, lean_score(acc, ai[q], nm, mt), key[q]);
         } else if (nm.tn > 0.0) {
-            // the same with more cells than registers: the estimates are formed twice, once for their maximum and once
-            // to pick the cells that get the exact formula
+            // The same with more cells than registers.  A lane keeps its best estimate with its cell, and its second
+            // best: when no lane's second best comes within the margin of the wave's maximum - the usual case - only
+            // the lanes' best cells can qualify and one pass over the cells is enough; otherwise the estimates are
+            // formed a second time to pick every cell that gets the exact formula.
             const float rn = __builtin_amdgcn_rcpf(nm.p2f);
-            float m = -FLT_MAX;
-            for (int i = lane; i < ncell; i += SLAM_WG) {
-                const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
-                const int x = cx * L.step, y = (r0 + cy) * L.step;
-                if (L.amask && L.amask[y * L.aw + x] == 0) continue;
-                const int ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
-                const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
-                if (SI != 0u) m = fmaxf(m, (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn);
-                else if (mt) m = fmaxf(m, 0.f);
-            }
-            m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
-            const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+            float m1 = -FLT_MAX, m2 = -FLT_MAX;
+            int i1 = 0;
             for (int i = lane; i < ncell; i += SLAM_WG) {
                 const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                 const int x = cx * L.step, y = (r0 + cy) * L.step;
@@ -525,7 +517,29 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 float est = -FLT_MAX;
                 if (SI != 0u) est = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
                 else if (mt) est = 0.f;
-                if (est != -FLT_MAX && est >= keep_from) best_update(b, lean_score(acc, ai, nm, mt), (y << 16) | x);
+                if (est > m1) { m2 = m1; m1 = est; i1 = i; }
+                else m2 = fmaxf(m2, est);                  // a tie with the best counts as a second candidate
+            }
+            const float m = __uint_as_float(wave_max_u32(m1 >= 0.f ? __float_as_uint(m1) : 0u));
+            const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+            if (__ballot(m2 != -FLT_MAX && m2 >= keep_from) == 0ull) {
+                if (m1 != -FLT_MAX && m1 >= keep_from) {
+                    const int cy = (int)(((float)i1 + 0.5f) * rnx), cx = i1 - cy * nx;
+                    const int x = cx * L.step, y = (r0 + cy) * L.step;
+                    best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b) : i1, nm, mt), (y << 16) | x);
+                }
+            } else {
+                for (int i = lane; i < ncell; i += SLAM_WG) {
+                    const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+                    const int x = cx * L.step, y = (r0 + cy) * L.step;
+                    if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+                    const int ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                    const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
+                    float est = -FLT_MAX;
+                    if (SI != 0u) est = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+                    else if (mt) est = 0.f;
+                    if (est != -FLT_MAX && est >= keep_from) best_update(b, lean_score(acc, ai, nm, mt), (y << 16) | x);
+                }
             }
         } else {
             for (int i = lane; i < ncell; i += SLAM_WG) {
