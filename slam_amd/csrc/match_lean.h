@@ -140,7 +140,7 @@ __device__ __forceinline__ float lean_score(const lds_u32* acc, int ai, const No
 // One entry of the lists for the NC cells of a unit: cc += <window, P0>, si += <window & M, window & M>.  A tile entry
 // holds the byte windows W0 (bytes 0..3 from its position) and W3 (bytes 3..6); W1 and W2 are picked out of the two.
 template <int NC, bool MASKED>
-__device__ __forceinline__ void lean_step(const lds_u8* wp, unsigned P0, unsigned M, unsigned (&cc)[NC], unsigned (&si)[NC]) {
+__device__ __forceinline__ void lean_step(const lds_u8* wp, unsigned P0, unsigned M, unsigned sel, unsigned (&cc)[NC], unsigned (&si)[NC]) {
     if (NC == 4) {
         const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
         const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
@@ -151,15 +151,21 @@ __device__ __forceinline__ void lean_step(const lds_u8* wp, unsigned P0, unsigne
         cc[2 % NC] = __builtin_amdgcn_udot4(w2, P0, cc[2 % NC], false); si[2 % NC] = __builtin_amdgcn_udot4(m2, m2, si[2 % NC], false);
         cc[3 % NC] = __builtin_amdgcn_udot4(w3, P0, cc[3 % NC], false); si[3 % NC] = __builtin_amdgcn_udot4(m3, m3, si[3 % NC], false);
     } else {
-        // the cell's window starts k = 0..3 bytes into the entry: k = 0 and 3 are stored, 1 and 2 picked
-        const unsigned k = (unsigned)(reinterpret_cast<unsigned long long>(wp)) & 7u;     // entries are 8-byte aligned; k rides in the low bits
-        const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp - k);
+        // the cell's window starts k = 0..3 bytes into the entry (k = 0 and 3 are stored, 1 and 2 picked): k is the same
+        // for every entry of a unit, so the caller passes the entry-aligned base and the byte selector (lean_window_sel)
+        const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
         const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
-        const unsigned sel = k == 0 ? 0x03020100u : k == 1 ? 0x05030201u : k == 2 ? 0x06050302u : 0x07060504u;
         const unsigned w = __builtin_amdgcn_perm(w3, w0, sel);
         const unsigned m0 = MASKED ? (w & M) : w;
         cc[0] = __builtin_amdgcn_udot4(w, P0, cc[0], false); si[0] = __builtin_amdgcn_udot4(m0, m0, si[0], false);
     }
+}
+
+// v_perm_b32 selector of the byte window that starts k = 0..3 bytes into a tile entry {W0, W3}: bytes k .. k + 3 of the
+// seven the entry holds (W3's bytes 0..3 are the entry's bytes 3..6, selector values 4..7)
+__device__ __forceinline__ unsigned lean_window_sel(unsigned k) {
+    const unsigned a = k & 1u ? 0x05030201u : 0x03020100u, b = k & 1u ? 0x07060504u : 0x06050302u;
+    return k & 2u ? b : a;
 }
 
 // Tasks are dealt slice-major (task = slice * nunits + unit): neighbouring lanes then hold neighbouring units of one
@@ -179,7 +185,8 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
         const int uq = (int)(((float)unit + 0.5f) * rdu), um = unit - uq * div_units;
         unsigned tb;                                       // byte offset of the unit's first window in the tile
         if (NC == 4) tb = (unsigned)(um * tp + uq) * 8u;
-        else { const int bx = o + um * step; tb = (unsigned)((uq * step) * tp + (bx >> 2)) * 8u + (unsigned)(bx & 3); }
+        unsigned sel = 0;
+        if (NC != 4) { const int bx = o + um * step; tb = (unsigned)((uq * step) * tp + (bx >> 2)) * 8u; sel = lean_window_sel((unsigned)bx & 3u); }
         const lds_u8* tl = tile + tb;
         unsigned cc[NC], si[NC];
 #pragma unroll
@@ -191,14 +198,14 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
             for (; e + 4 <= na; e += 4) {
                 const unsigned long long c0 = q0, c1 = q1, c2 = q2, c3 = q3;
                 q0 = ea[e + 4]; q1 = ea[e + 5]; q2 = ea[e + 6]; q3 = ea[e + 7];
-                lean_step<NC, false>(tl + (unsigned)(c0 >> 32), (unsigned)c0, 0u, cc, si);
-                lean_step<NC, false>(tl + (unsigned)(c1 >> 32), (unsigned)c1, 0u, cc, si);
-                lean_step<NC, false>(tl + (unsigned)(c2 >> 32), (unsigned)c2, 0u, cc, si);
-                lean_step<NC, false>(tl + (unsigned)(c3 >> 32), (unsigned)c3, 0u, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c0 >> 32), (unsigned)c0, 0u, sel, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c1 >> 32), (unsigned)c1, 0u, sel, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c2 >> 32), (unsigned)c2, 0u, sel, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c3 >> 32), (unsigned)c3, 0u, sel, cc, si);
             }
-            if (e < na) lean_step<NC, false>(tl + (unsigned)(q0 >> 32), (unsigned)q0, 0u, cc, si);
-            if (e + 1 < na) lean_step<NC, false>(tl + (unsigned)(q1 >> 32), (unsigned)q1, 0u, cc, si);
-            if (e + 2 < na) lean_step<NC, false>(tl + (unsigned)(q2 >> 32), (unsigned)q2, 0u, cc, si);
+            if (e < na) lean_step<NC, false>(tl + (unsigned)(q0 >> 32), (unsigned)q0, 0u, sel, cc, si);
+            if (e + 1 < na) lean_step<NC, false>(tl + (unsigned)(q1 >> 32), (unsigned)q1, 0u, sel, cc, si);
+            if (e + 2 < na) lean_step<NC, false>(tl + (unsigned)(q2 >> 32), (unsigned)q2, 0u, sel, cc, si);
         }
         {   // partly masked groups (and the padding entries, mask 0)
             const lds_u64* eb = list + nA1 + slice * nb;
@@ -210,10 +217,10 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
                 const unsigned long long c0 = q0, c1 = q1;
                 const unsigned k0 = m0, k1 = m1;
                 q0 = eb[e + 2]; q1 = eb[e + 3]; m0 = mb[e + 2]; m1 = mb[e + 3];
-                lean_step<NC, true>(tl + (unsigned)(c0 >> 32), (unsigned)c0, k0, cc, si);
-                lean_step<NC, true>(tl + (unsigned)(c1 >> 32), (unsigned)c1, k1, cc, si);
+                lean_step<NC, true>(tl + (unsigned)(c0 >> 32), (unsigned)c0, k0, sel, cc, si);
+                lean_step<NC, true>(tl + (unsigned)(c1 >> 32), (unsigned)c1, k1, sel, cc, si);
             }
-            if (e < nb) lean_step<NC, true>(tl + (unsigned)(q0 >> 32), (unsigned)q0, m0, cc, si);
+            if (e < nb) lean_step<NC, true>(tl + (unsigned)(q0 >> 32), (unsigned)q0, m0, sel, cc, si);
         }
         if (t0 + lane < ntask) {
 #pragma unroll
