@@ -270,7 +270,8 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
     const FastTile bt = fast_tile_of_block(ntx, nty, nframes);
     const int tx = bt.tx, ty = bt.ty, frame = bt.frame;
     if (frame >= nframes) return;                               // the last round of 8 frames may be short
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // the wavefront's index as a scalar: row numbers, row addresses and the tests on them then stay on the scalar unit
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint8_t* im = frames + (long long)frame * frame_stride;
     const int cx0 = tx * FAST_TW, y0 = ty * FAST_TH;            // first output column / row of the tile
     unsigned* fs = scratch + (size_t)frame * fast_frame_words(h, ntx);
@@ -303,13 +304,13 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
             va[q] = 0; vb[q] = 0;
             if (r < FAST_PR && y >= 0 && y < h) {                // wave-uniform
                 const uint8_t* src = im + (long long)y * pitch;
-                if (in_a) va[q] = *reinterpret_cast<const unsigned*>(src + xa);
+                if (in_a) va[q] = *reinterpret_cast<const unsigned*>(src + (unsigned)xa);      // in_a: xa >= 0
                 else if (edge_a) {
 #pragma unroll
                     for (int b2 = 0; b2 < 4; b2++)
                         if (xa + b2 >= 0 && xa + b2 < w) va[q] |= (unsigned)src[xa + b2] << (8 * b2);
                 }
-                if (in_b) vb[q] = *reinterpret_cast<const unsigned*>(src + xb);
+                if (in_b) vb[q] = *reinterpret_cast<const unsigned*>(src + (unsigned)xb);
                 else if (edge_b) {
 #pragma unroll
                     for (int b2 = 0; b2 < 4; b2++)
