@@ -298,6 +298,26 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
         const bool in_a = aligned && xa >= 0 && xa + 3 < w, in_b = aligned && lane < DW - 64 && xb >= 0 && xb + 3 < w;
         const bool edge_a = !in_a && xa + 3 >= 0 && xa < w, edge_b = !in_b && lane < DW - 64 && xb + 3 >= 0 && xb < w;
         unsigned va[RW], vb[RW];
+        if (aligned && (w & 3) == 0) {
+            // the usual case - a dword lies inside the image or outside it, never across its edge: every lane loads
+            // from a column clamped into the row and picks the value or zero afterwards, without per-lane branches
+            const unsigned xac = in_a ? (unsigned)xa : 0u, xbc = in_b ? (unsigned)xb : 0u;
+#pragma unroll
+            for (int q = 0; q < RW; q++) {
+                const int r = wid + 4 * q, y = y0 - 4 + r;
+                va[q] = 0; vb[q] = 0;
+                if (r < FAST_PR && y >= 0 && y < h) {            // wave-uniform
+                    const uint8_t* src = im + (long long)y * pitch;
+                    va[q] = *reinterpret_cast<const unsigned*>(src + xac);
+                    vb[q] = *reinterpret_cast<const unsigned*>(src + xbc);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RW; q++) {
+                va[q] = in_a ? va[q] : 0u;
+                vb[q] = in_b ? vb[q] : 0u;
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < RW; q++) {
             const int r = wid + 4 * q, y = y0 - 4 + r;
