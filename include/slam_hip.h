@@ -50,17 +50,18 @@ int slam_hip_destroy(slam_ctx* ctx);
 /* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the context's own. */
 int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream);
 int slam_hip_synchronize(slam_ctx* ctx);
-/* LDS bytes each search job (one wavefront) may use: a multiple of 1024 in [4096, 64512], default
- * 9216 (16 jobs then share a CU's 160 KB with room for their static LDS, as many as the kernels'
- * registers allow; line walks: 12288, 12 per CU).  Less LDS never
- * adds jobs per CU; more LDS cuts large templates into fewer chunks at the price of fewer jobs per CU.
- * Results do not depend on it. */
+/* LDS bytes each search job (one wavefront) may use: a multiple of 64 in [4096, 64512], default
+ * 9664 (a CU's 160 KB are handed out in granules of 1280 bytes; with the walk kernel's 576 static bytes a job
+ * then takes 8 granules and 16 jobs share a CU, as many as the kernels' registers allow; line walks: 12800,
+ * 12 per CU).  Less LDS never adds jobs per CU; more LDS cuts large templates into fewer chunks at the price of
+ * fewer jobs per CU.  Results do not depend on it. */
 int slam_hip_set_match_lds(slam_ctx* ctx, int bytes);
 /* LDS bytes per job of the lean point-walk kernel (the first of the two kernels behind slam_hip_track_batch[_d]): a
- * multiple of 1024 in [4096, 65536], default 8192 (20 walks share a CU).  A walk any of whose levels needs more - the
- * image tile under the window, the template's entry list and the score cells together - is left to the general
- * kernel, so raise it for templates beyond about 24x24 at full resolution (31x31 templates in 17x17 windows need
- * 12288).  Results do not depend on it. */
+ * multiple of 64 in [4096, 65536], default 7680 (6 of the CU's 128 LDS granules of 1280 bytes: 21 walks share a
+ * CU; only multiples of 1280 change that number).  A walk any of whose levels needs more - the image tile under the
+ * window, the template's entry list and the score cells together - is left to the general kernel, so raise it for
+ * templates beyond about 22x22 at full resolution (31x31 templates in 17x17 windows need 11520).  Results do not
+ * depend on it. */
 int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes);
 /* Text of the last error on ctx (or of the last failed slam_hip_create when ctx is NULL). */
 const char* slam_hip_last_error_string(const slam_ctx* ctx);

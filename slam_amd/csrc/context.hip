@@ -49,6 +49,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     c->no_lean = (nl && nl[0] == '1') ? 1 : 0;
     const char* wk = getenv("SLAM_HIP_WALK_LDS_KB");
     if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) { c->lean_lds_bytes = atoi(wk) * 1024; c->lean_lds_user = 1; }
+    const char* wb = getenv("SLAM_HIP_WALK_LDS_BYTES");
+    if (wb && atoi(wb) >= 4096 && atoi(wb) <= 65536) { c->lean_lds_bytes = atoi(wb) & ~255; c->lean_lds_user = 1; }
     const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");
     if (sk && atoi(sk) >= 4 && atoi(sk) <= 64) c->lean_match_lds_bytes = atoi(sk) * 1024;
     const char* sm = getenv("SLAM_HIP_SEARCH_LEAN_MIN");
@@ -88,8 +90,8 @@ extern "C" int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream) {
 
 extern "C" int slam_hip_set_match_lds(slam_ctx* ctx, int bytes) {
     if (!ctx) return SLAM_HIP_EINVAL;
-    if (bytes < 4096 || bytes > 64512 || (bytes & 1023))      // the walk kernel adds 576 B of static LDS: 64 KB per workgroup in all
-        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_match_lds: %d not a multiple of 1024 in [4096, 64512]", bytes);
+    if (bytes < 4096 || bytes > 64512 || (bytes & 63))        // the walk kernel adds 576 B of static LDS: 64 KB per workgroup in all
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_match_lds: %d not a multiple of 64 in [4096, 64512]", bytes);
     ctx->match_lds_bytes = bytes;
     ctx->line_lds_bytes = bytes;
     return SLAM_HIP_OK;
@@ -97,8 +99,8 @@ extern "C" int slam_hip_set_match_lds(slam_ctx* ctx, int bytes) {
 
 extern "C" int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes) {
     if (!ctx) return SLAM_HIP_EINVAL;
-    if (bytes < 4096 || bytes > 65536 || (bytes & 1023))
-        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_walk_lds: %d not a multiple of 1024 in [4096, 65536]", bytes);
+    if (bytes < 4096 || bytes > 65536 || (bytes & 63))
+        return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_walk_lds: %d not a multiple of 64 in [4096, 65536]", bytes);
     ctx->lean_lds_bytes = bytes;
     ctx->lean_lds_user = 1;
     return SLAM_HIP_OK;

@@ -917,7 +917,7 @@ void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job
         }
         if (worst != INT_MAX && worst <= 24576) need = std::max(need, worst);      // larger walks go to the general kernel anyway
     }
-    const int rounded = (need + 1023) / 1024 * 1024;
+    const int rounded = (need + 1279) / 1280 * 1280;        // whole LDS granules (slam_internal.h)
     if (rounded > ctx->lean_lds_bytes) ctx->lean_lds_once = rounded;
 }
 

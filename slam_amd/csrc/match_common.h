@@ -17,7 +17,11 @@ __device__ unsigned long long* g_slam_stamps = nullptr;
 __device__ __forceinline__ void slam_stamp(int& slot, int id) {
     if (g_slam_stamps && threadIdx.x == 0 && slot < SLAM_STAMP_SLOTS) {
         unsigned long long t;
+#ifdef SLAM_STAMPS_REALTIME       // the 100 MHz counter all CUs share (launch timelines) instead of the CU's shader clock (phase costs)
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+#else
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+#endif
         g_slam_stamps[(size_t)blockIdx.x * SLAM_STAMP_SLOTS + slot] = (t << 8) | (unsigned)id;
     }
     slot++;

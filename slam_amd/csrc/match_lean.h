@@ -79,7 +79,7 @@ struct LeanLevel {           // wave-uniform description of one level's search
 
 struct LeanOut { int x, y; float response, dx, dy; bool ok; };
 
-#define LEAN_MAX_S 16
+#define LEAN_MAX_S 8
 
 // diagnostic build (-DSLAM_LEAN_DEBUG): job 0 says why a walk was left to the general kernel
 #ifdef SLAM_LEAN_DEBUG
@@ -98,8 +98,8 @@ __device__ __forceinline__ LeanSlices lean_pick_slices(int nunits, int nA, int n
     LeanSlices best = {1, nA, nB};
     int best_c = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        constexpr int cand[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int q = 0; q < 6; q++) {
+        constexpr int cand[6] = {1, 2, 3, 4, 6, 8};          // at most LEAN_MAX_S
         const int s = cand[q];
         const int passes = (nunits * s + SLAM_WG - 1) >> 6;
         const int a = nA / s;
@@ -110,6 +110,11 @@ __device__ __forceinline__ LeanSlices lean_pick_slices(int nunits, int nA, int n
     return best;
 }
 
+// Entries the lists hold at most: the template's groups, the padding of the masked part to a multiple of the slice count
+// (at most S - 1 null entries) and the entries the loops read ahead of their use (four past the all-kept part of the
+// last slice, two past the masked part).
+__host__ __device__ __forceinline__ int lean_cap(int NG) { return NG + LEAN_MAX_S + 4; }
+
 // LDS bytes a level needs (INT_MAX: a shape this path does not take), with the window's column phase x0 & 3 at its
 // worst, so that the answer depends on sizes only and a walk can be turned away before its first level is searched.
 __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized) {
@@ -119,7 +124,7 @@ __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah
     const int tp = (cols + G - 1) | 1;
     const int trows = ah + th - 1;
     const int nacc = strips ? cols * ah * 4 : nx * ny;
-    const int cap = NG + LEAN_MAX_S + 8;
+    const int cap = lean_cap(NG);
     const int tile_bytes = (trows * tp * 8 + 15) & ~15;
     const int raw_bytes = NG * 8 + (resized ? (G * 4 + th) * 8 : 0);
     // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
@@ -256,7 +261,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int rstep = strips ? 1 : L.step;                 // image rows from one unit row to the next
     const int upr = strips ? cols : nx;                    // units per row
     const int cpu = strips ? 4 : 1;                        // cells per unit
-    const int cap = NG + LEAN_MAX_S + 8;                   // room for the padding entries and for reads a few entries ahead
+    const int cap = lean_cap(NG);                          // room for the padding entries and for reads a few entries ahead
     const int list_bytes = cap * 8, marr_bytes = (cap * 4 + 15) & ~15;
     int bh = rows_all, nblk = 1;                           // unit rows per block, blocks
     if (!SEARCH) {

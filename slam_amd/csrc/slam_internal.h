@@ -19,10 +19,12 @@ struct slam_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     char err[512] = {0};
-    int line_lds_bytes = 12 * 1024;    // the same for line walks: 12 jobs per CU (3 per SIMD), large descriptors
-    int match_lds_bytes = 9 * 1024;    // LDS per search job: 16 jobs share a CU's 160 KB, as many as its registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
+    // A CU's 160 KB of LDS are handed out in 128 granules of 1280 bytes: a workgroup that asks for n bytes occupies
+    // ceil(n / 1280) of them, so budgets are multiples of 1280 (less any static LDS of the kernel).
+    int line_lds_bytes = 12800;        // line walks: 10 granules, 12 jobs per CU (3 per SIMD, as many as the registers allow), large descriptors
+    int match_lds_bytes = 9664;        // LDS per search job: with track_kernel's 576 static bytes 8 granules, 16 jobs per CU, as many as the registers allow (SLAM_HIP_MATCH_LDS_KB / slam_hip_set_match_lds)
     int force_direct = 0;   // SLAM_HIP_FORCE_DIRECT=1: search by direct evaluation (cross-check of the tiled core)
-    int lean_lds_bytes = 8192;         // LDS per job of the lean walk kernel: 20 jobs per CU
+    int lean_lds_bytes = 7680;         // LDS per job of the lean walk kernel: 6 granules, 21 jobs per CU
     int lean_lds_user = 0;             // set by the caller (slam_hip_set_walk_lds, SLAM_HIP_WALK_LDS_KB): never sized automatically
     int lean_lds_once = 0;             // budget of the next walk launch only (slam_size_walk_lds), 0 = lean_lds_bytes
     int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: walks and searches skip the lean kernels (cross-check of them)

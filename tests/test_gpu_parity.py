@@ -409,7 +409,7 @@ def test_track_matches_oracle(ctx, oracle, w, h, subs, nfeat, tsize, min_found):
         pyr.close()
 
 
-@pytest.mark.parametrize("lds", [4096, 8192, 9216, 12288, 32768, 64512])
+@pytest.mark.parametrize("lds", [4096, 7680, 8192, 9664, 12800, 32768, 64512])
 def test_results_do_not_depend_on_the_lds_budget(oracle, lds):
     """The LDS a job may use only changes how its work is cut into blocks and chunks (slam_hip_set_match_lds):
     walks, single searches with score maps and line-style searches give the oracle's results at every budget."""
