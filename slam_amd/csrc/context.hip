@@ -53,6 +53,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     if (wb && atoi(wb) >= 4096 && atoi(wb) <= 65536) { c->lean_lds_bytes = atoi(wb) & ~255; c->lean_lds_user = 1; }
     const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");
     if (sk && atoi(sk) >= 4 && atoi(sk) <= 64) c->lean_match_lds_bytes = atoi(sk) * 1024;
+    const char* sb = getenv("SLAM_HIP_SEARCH_LDS_BYTES");
+    if (sb && atoi(sb) >= 4096 && atoi(sb) <= 65536) c->lean_match_lds_bytes = atoi(sb) & ~63;
     const char* sm = getenv("SLAM_HIP_SEARCH_LEAN_MIN");
     if (sm && atoi(sm) >= 1) c->lean_match_min_jobs = atoi(sm);
     const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");

@@ -33,7 +33,8 @@ constexpr int FAST_PR = FAST_TH + 8;            // pixel rows
 #ifndef FAST_DENSE_LANES
 #define FAST_DENSE_LANES 24                     // lanes of a row with a candidate after half the pair test: beyond, the other half runs
 #endif
-constexpr int FAST_LIST = 768;                  // candidate slots per wavefront; a row adds at most 2 * FAST_CW (one per pixel and polarity)
+constexpr int FAST_LIST = 600;                  // candidate slots per wavefront; a row adds at most 2 * FAST_CW (one per pixel and polarity).  With 600 the
+                                                // kernel's LDS is 23024 bytes = 18 of the CU's 128 granules of 1280 bytes: 7 workgroups per CU (768: 20 granules, 6)
 
 struct FastPlan {
     int ntx, nty;     // tiles per row / column of tiles
@@ -257,7 +258,7 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
 }
 
 
-__global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
+__global__ __launch_bounds__(FAST_WG, 7) void fast_tile_kernel(
     const uint8_t* __restrict__ frames, int w, int h, long long pitch, long long frame_stride,
     int threshold, int nonmax, int ntx, int nty, int nframes, unsigned* __restrict__ scratch) {
     __shared__ __attribute__((aligned(16))) unsigned char px_s[FAST_PR * FAST_PPITCH];    // pixels
@@ -389,42 +390,55 @@ __global__ __launch_bounds__(FAST_WG, 6) void fast_tile_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // One scan lists the candidates of all 8 rows when they fit the list - the usual case; otherwise one scan per half
+    // (4 rows), and row by row only where even a half does not fit.  Every lane writes its own entries.
+    auto list_bits = [&](unsigned bb, int row0, int pos) {       // bb: four rows of flags (fast_rows_shared), first row row0
+        while (bb) {
+            const int bi = __builtin_ctz(bb);
+            bb &= bb - 1u;
+            const int rr = row0 + ((bi & 15) >> 2), j = (bi & 1) + 2 * (bi >> 4);
+            mylist[pos++] = (unsigned short)((((unsigned)bi & 2u) << 14) | ((unsigned)rr << 8) | (unsigned)(4 * lane + j));
+        }
+        return pos;
+    };
     const unsigned mine8 = (unsigned)(__popc(cand_lo) + __popc(cand_hi));
     if (__ballot(mine8 != 0u) != 0ull) {                         // else: no candidate in the 8 rows, nothing to list
         const unsigned incl8 = wave_scan_incl(mine8);
         const int tot8 = __builtin_amdgcn_readlane((int)incl8, 63);
         if (tot8 <= FAST_LIST) {
-            // the usual case: the candidates of all 8 rows fit the list - one scan, every lane writes its own entries
-            int pos = (int)(incl8 - mine8);
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                unsigned bb = half ? cand_hi : cand_lo;
-                while (bb) {
-                    const int bi = __builtin_ctz(bb);
-                    bb &= bb - 1u;
-                    const int rr = half * 4 + ((bi & 15) >> 2), j = (bi & 1) + 2 * (bi >> 4);
-                    mylist[pos++] = (unsigned short)((((unsigned)bi & 2u) << 14) | ((unsigned)rr << 8) | (unsigned)(4 * lane + j));
-                }
-            }
+            list_bits(cand_hi, 4, list_bits(cand_lo, 0, (int)(incl8 - mine8)));
             score_list(tot8);
         } else {
-            // dense rows: row by row, the list scored whenever another row (at most 2 * FAST_CW entries) might not fit
-            int n = 0;
-            for (int rr = 0; rr <= rows_per_wave; rr++) {
-                if (n > 0 && (rr == rows_per_wave || n + 2 * FAST_CW > FAST_LIST)) { score_list(n); n = 0; }
-                if (rr == rows_per_wave) break;
-                const unsigned cbd = ((rr < 4 ? cand_lo : cand_hi) >> (4 * (rr & 3))) & 0x000F000Fu;
-                if (__ballot(cbd != 0u) != 0ull) {
-                    const unsigned mine = (unsigned)__popc(cbd);
-                    const unsigned incl = wave_scan_incl(mine);
-                    int pos = n + (int)(incl - mine);
+            for (int half = 0; half < 2; half++) {
+                const unsigned bits = half ? cand_hi : cand_lo;
+                const unsigned mine4 = (unsigned)__popc(bits);
+                if (__ballot(mine4 != 0u) == 0ull) continue;
+                const unsigned incl4 = wave_scan_incl(mine4);
+                const int tot4 = __builtin_amdgcn_readlane((int)incl4, 63);
+                if (tot4 <= FAST_LIST) {
+                    list_bits(bits, 4 * half, (int)(incl4 - mine4));
+                    score_list(tot4);
+                    continue;
+                }
+                // dense rows: row by row, the list scored whenever another row (at most 2 * FAST_CW entries) might not fit
+                int n = 0;
+                for (int rq = 0; rq <= 4; rq++) {
+                    if (n > 0 && (rq == 4 || n + 2 * FAST_CW > FAST_LIST)) { score_list(n); n = 0; }
+                    if (rq == 4) break;
+                    const int rr = 4 * half + rq;
+                    const unsigned cbd = (bits >> (4 * rq)) & 0x000F000Fu;
+                    if (__ballot(cbd != 0u) != 0ull) {
+                        const unsigned mine = (unsigned)__popc(cbd);
+                        const unsigned incl = wave_scan_incl(mine);
+                        int pos = n + (int)(incl - mine);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int bit = (j & 1) + 16 * (j >> 1);
-                        if ((cbd >> bit) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
-                        if ((cbd >> (bit + 2)) & 1u) mylist[pos++] = (unsigned short)(0x8000u | (rr << 8) | (4 * lane + j));
+                        for (int j = 0; j < 4; j++) {
+                            const int bit = (j & 1) + 16 * (j >> 1);
+                            if ((cbd >> bit) & 1u) mylist[pos++] = (unsigned short)((rr << 8) | (4 * lane + j));
+                            if ((cbd >> (bit + 2)) & 1u) mylist[pos++] = (unsigned short)(0x8000u | (rr << 8) | (4 * lane + j));
+                        }
+                        n += __builtin_amdgcn_readlane((int)incl, 63);
                     }
-                    n += __builtin_amdgcn_readlane((int)incl, 63);
                 }
             }
         }

@@ -257,7 +257,13 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
 // matchTemplate's normalisation whatever the stride (matching.cpp:151-153), and an area mask removes cells only
 // when it is exact (matching.cpp:157-163).  Any other job is appended to the queue for match_kernel; nothing is
 // written to `out` for it here.
-__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_lean_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
+// The lean single-search kernel is built for 5 wavefronts per SIMD (96 registers, a handful spilled): with 7680 bytes of
+// LDS per search (6 granules, slam_internal.h) 20 searches share a CU instead of 16, which pays for the spills and
+// for the lower row blocks (C1: 0.245 -> 0.228 ms per 16384 searches; at 4 wavefronts and 10240 bytes 0.245, at 5 and 10240 0.261).
+#ifndef SLAM_MIN_WAVES_LEAN_SEARCH
+#define SLAM_MIN_WAVES_LEAN_SEARCH 5
+#endif
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LEAN_SEARCH) void match_lean_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes, const float* scores,
                                                         slam_match_result* __restrict__ out, int lds_total, int* __restrict__ queue, int cnt) {
