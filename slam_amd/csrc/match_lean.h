@@ -487,31 +487,69 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             // can hold the maximum or tie with it, and only those are scored with the exact formula.  -FLT_MAX marks cells
             // that are not visited or whose exact score is NaN (an all-zero window under the F32 formula).
             const float rn = __builtin_amdgcn_rcpf(nm.p2f);
-            float est[NQ], m = -FLT_MAX;
-            int ai[NQ], key[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                est[q] = -FLT_MAX; ai[q] = 0; key[q] = 0;
-                if (q * SLAM_WG < ncell) {
-                    const int i = q * SLAM_WG + lane;
+            if constexpr (SEARCH) {
+                // the single-search kernel runs at 96 registers (5 wavefronts per SIMD): a cell's accumulator index and key
+                // are formed again for the few cells scored exactly instead of being kept for all of them
+                float est[NQ], m = -FLT_MAX;
+                // (cell q * 64 + lane: accumulator index and the key (y << 16) | x)
+                auto cell_of = [&](int i, int& ai, int& key) {
                     const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                     const int x = cx * L.step, y = (r0 + cy) * L.step;
-                    if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0)) {
-                        ai[q] = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
-                        key[q] = (y << 16) | x;
-                        const unsigned CC = acc[2 * ai[q]], SI = acc[2 * ai[q] + 1];
-                        if (SI != 0u) est[q] = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
-                        else if (mt) est[q] = 0.f;           // matchTemplate scores an all-zero window 0, the F32 formula NaN
-                    }
-                    m = fmaxf(m, est[q]);
-                }
-            }
-            // estimates are >= 0 or the marker, so their bit patterns order like the values once the marker is mapped to 0
-            m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
-            const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+                    ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                    key = (y << 16) | x;
+                    return !(L.amask && L.amask[y * L.aw + x] == 0);
+                };
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
-                if (q * SLAM_WG < ncell && est[q] != -FLT_MAX && est[q] >= keep_from) best_update(b, lean_score(acc, ai[q], nm, mt), key[q]);
+                for (int q = 0; q < NQ; q++) {
+                    est[q] = -FLT_MAX;
+                    if (q * SLAM_WG < ncell) {
+                        const int i = q * SLAM_WG + lane;
+                        int ai, key;
+                        if (i < ncell && cell_of(i, ai, key)) {
+                            const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
+                            if (SI != 0u) est[q] = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+                            else if (mt) est[q] = 0.f;           // matchTemplate scores an all-zero window 0, the F32 formula NaN
+                        }
+                        m = fmaxf(m, est[q]);
+                    }
+                }
+                // estimates are >= 0 or the marker, so their bit patterns order like the values once the marker is mapped to 0
+                m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
+                const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    if (q * SLAM_WG < ncell && est[q] != -FLT_MAX && est[q] >= keep_from) {
+                        int ai, key;
+                        cell_of(q * SLAM_WG + lane, ai, key);
+                        best_update(b, lean_score(acc, ai, nm, mt), key);
+                    }
+            } else {
+                float est[NQ], m = -FLT_MAX;
+                int ai[NQ], key[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    est[q] = -FLT_MAX; ai[q] = 0; key[q] = 0;
+                    if (q * SLAM_WG < ncell) {
+                        const int i = q * SLAM_WG + lane;
+                        const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
+                        const int x = cx * L.step, y = (r0 + cy) * L.step;
+                        if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0)) {
+                            ai[q] = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                            key[q] = (y << 16) | x;
+                            const unsigned CC = acc[2 * ai[q]], SI = acc[2 * ai[q] + 1];
+                            if (SI != 0u) est[q] = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
+                            else if (mt) est[q] = 0.f;           // matchTemplate scores an all-zero window 0, the F32 formula NaN
+                        }
+                        m = fmaxf(m, est[q]);
+                    }
+                }
+                // estimates are >= 0 or the marker, so their bit patterns order like the values once the marker is mapped to 0
+                m = __uint_as_float(wave_max_u32(m >= 0.f ? __float_as_uint(m) : 0u));
+                const float keep_from = m - 1e-5f * fmaxf(m, 1.f);
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+                    if (q * SLAM_WG < ncell && est[q] != -FLT_MAX && est[q] >= keep_from) best_update(b, lean_score(acc, ai[q], nm, mt), key[q]);
+            }
         } else if (nm.tn > 0.0) {
             // The same with more cells than registers.  A lane keeps its best estimate with its cell, and its second
             // best: when no lane's second best comes within the margin of the wave's maximum - the usual case - only
