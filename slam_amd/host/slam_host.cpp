@@ -327,6 +327,26 @@ void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const CameraState& sta
     }
 }
 
+void SLAM::matchPoints(const cv::Mat_<byte>& im, const CameraState& state, std::vector<Match>& matches, float threshold) {
+    const int stride = 3;                                   // matching.cpp:243
+    std::vector<float> subsamples;
+    subsamples.push_back(1.f);
+    subsamples.push_back(3.f);                              // matching.cpp:244-246
+    ImagePyramid<byte> pyramid(im, subsamples);
+    if (!pyramid.ok() || features.empty()) return;
+    std::vector<matf> p3ds(features.size());
+    for (size_t i = 0; i < features.size(); i++) {
+        if (features[i].iKalman < 0 || (size_t)features[i].iKalman >= kalman.points.size()) {
+            slamhip::failed(SLAM_HIP_EINVAL, "matchPoints", "feature without a point in kalman.points");
+            return;
+        }
+        p3ds[i] = kalman.getPt3d(features[i].iKalman);      // matching.cpp:252
+    }
+    std::vector<Match> found;
+    matchPoints(pyramid, state, features, p3ds, found, threshold, stride, nullptr);
+    matches.insert(matches.end(), found.begin(), found.end());
+}
+
 void SLAM::matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Projection>& features,
                        std::vector<Match>& matches, float threshold, int stride, std::vector<float>* responses) {
     matches.clear();

@@ -7,7 +7,7 @@
 //   SLAM::Feature::track           SLAM.hpp:62-65, feature.cpp:102-173
 //   SLAM::matchLines               SLAM.hpp:108-109, matching.cpp:271-310 (the image work of LineFeature::track)
 //   SLAM::getSortedKeyPoints       SLAM.hpp:118-119, new_point.cpp:113-127
-//   SLAM::matchPoints              SLAM.hpp:106-107, matching.cpp:230-269 (batched over features)
+//   SLAM::matchPoints              SLAM.hpp:106-107, matching.cpp:230-269 (the member call, and forms batched over features)
 // Nothing here throws, as nothing in the reference does: a device error (no GPU, failed allocation) or a rejected
 // argument gives the call's own sentinel - response -1 and (0,0) from matchFeatureInArea (matching.cpp:26-30), (-1,-1)
 // and -1 from Feature::track (feature.cpp:112-115), no matches, no keypoints, an empty Mat - and leaves its code and
@@ -172,4 +172,18 @@ public:
     // SLAM.hpp:118-119; fastThreshold is the mutable member of SLAM.hpp:22.
     void getSortedKeyPoints(const matb& im, size_t nMinPts, std::vector<cv::KeyPoint>& out) const;
     mutable float fastThreshold = 10.f;
+
+    // The reference's own member call, SLAM.hpp:106-107 / matching.cpp:230-269, on the members it reads: `features`
+    // and, of the filter (out of scope), the one thing the path asks it for - kalman.getPt3d(i), the 3x1 point of
+    // state entry i (kalman.hpp:32-34), kept here as the points the caller's filter last reported.  Builds the
+    // pyramid {1, 3} (matching.cpp:243-247), projects and tracks every feature with stride 3 in one device pass and
+    // appends Match(pos, i) when response > threshold (matching.cpp:254-255; like the reference it appends to
+    // `matches` without clearing it).  The debug overlay (matching.cpp:232-241, 262-268) is not drawn.
+    struct PointSource {
+        std::vector<matf> points;
+        matf getPt3d(int i) const { return points[(size_t)i]; }
+    };
+    std::vector<Feature> features;
+    PointSource kalman;
+    void matchPoints(const cv::Mat_<byte>& im, const CameraState& state, std::vector<Match>& matches, float threshold = .95f);
 };

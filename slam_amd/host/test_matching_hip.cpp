@@ -241,6 +241,24 @@ static bool test_project_track() {
     std::vector<SLAM::Match> matches;
     std::vector<float> resp;
     SLAM::matchPoints(pyramid, state, feats, p3ds, matches, 0.9f, 3, &resp);
+    {   // the reference's member call (SLAM.hpp:106-107) on the same features: it builds the pyramid {1, 3} itself
+        SLAM slam;
+        slam.features = feats;
+        slam.kalman.points = p3ds;                        // iKalman = k above
+        slam.features.back().iKalman = (int)p3ds.size() - 1;
+        std::vector<SLAM::Match> got;
+        got.push_back(SLAM::Match(cv::Point2f(-5.f, -5.f), -1));     // matches are appended, not replaced (matching.cpp:255)
+        slam.matchPoints(im, state, got, 0.9f);
+        if (got.size() != matches.size() + 1 || got[0].iFeature != -1 || matches.empty()) {
+            printf("member matchPoints: %zu matches, expected %zu + 1\n", got.size(), matches.size());
+            return false;
+        }
+        for (size_t k = 0; k < matches.size(); k++)
+            if (got[k + 1].iFeature != matches[k].iFeature || got[k + 1].pos.x != matches[k].pos.x || got[k + 1].pos.y != matches[k].pos.y) {
+                printf("member matchPoints: match %zu differs\n", k);
+                return false;
+            }
+    }
     size_t nm = 0, tracked = 0;
     for (size_t k = 0; k < feats.size(); k++) {
         const SLAM::Feature& ft = feats[k];
