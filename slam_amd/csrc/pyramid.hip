@@ -42,12 +42,19 @@ struct PyrArgs {
 // (with all four 11-bit weights equal to 1024 the two >>16 steps are exact).  Each thread produces 4
 // adjacent output pixels from 4*S contiguous source bytes of two rows; xn is a multiple of 4 and the
 // source is 16-byte aligned (checked on the host).
+// The four source bytes of one output pixel gathered into a dword (v_perm_b32: selector bytes 0..3 pick from lo,
+// 4..7 from hi), summed with the rounding term by one v_sad_u8 against zero, and shifted: (a + b + c + d + 2) >> 2.
+__device__ __forceinline__ uint32_t box_px(uint32_t hi, uint32_t lo, uint32_t sel) {
+    return __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(hi, lo, sel), 0u, 2u) >> 2;
+}
+
 template <int S>
 __device__ __forceinline__ void box_tile(const uint8_t* __restrict__ src, long long spitch, uint8_t* __restrict__ dst,
                                          long long dpitch, int xb, int xn, int yb, int yn) {
     const int ncg = xn >> 2;
     const int items = yn * ncg;
     const float rncg = 1.0f / (float)ncg;
+#pragma unroll 2
     for (int item = threadIdx.x; item < items; item += 256) {
         const int row = (int)(((float)item + 0.5f) * rncg);           // items <= 2^13: exact
         const int cg = item - row * ncg;
@@ -55,32 +62,25 @@ __device__ __forceinline__ void box_tile(const uint8_t* __restrict__ src, long l
         const uint8_t* r1 = r0 + spitch;
         uint32_t packed;
         if (S == 2) {
+            // output pixel j: bytes 2j, 2j + 1 of both rows' 8 bytes
             const uint2 u = *reinterpret_cast<const uint2*>(r0), v = *reinterpret_cast<const uint2*>(r1);
-            // 16-bit lanes: sums of byte pairs
-            const uint32_t ex = (u.x & 0x00ff00ffu) + ((u.x >> 8) & 0x00ff00ffu) + (v.x & 0x00ff00ffu) + ((v.x >> 8) & 0x00ff00ffu) + 0x00020002u;
-            const uint32_t ey = (u.y & 0x00ff00ffu) + ((u.y >> 8) & 0x00ff00ffu) + (v.y & 0x00ff00ffu) + ((v.y >> 8) & 0x00ff00ffu) + 0x00020002u;
-            const uint32_t qx = (ex >> 2) & 0x00ff00ffu, qy = (ey >> 2) & 0x00ff00ffu;
-            packed = (qx & 0xffu) | ((qx >> 8) & 0xff00u) | ((qy & 0xffu) << 16) | ((qy >> 16) << 24);
+            packed = box_px(v.x, u.x, 0x05040100u) | (box_px(v.x, u.x, 0x07060302u) << 8) |
+                     (box_px(v.y, u.y, 0x05040100u) << 16) | (box_px(v.y, u.y, 0x07060302u) << 24);
         } else if (S == 4) {
+            // output pixel j: bytes 1, 2 of dword j of both rows
             const uint4 u = *reinterpret_cast<const uint4*>(r0), v = *reinterpret_cast<const uint4*>(r1);
-            const uint32_t a[4] = {u.x, u.y, u.z, u.w}, b[4] = {v.x, v.y, v.z, v.w};
-            packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t t = ((a[j] >> 8) & 0xffu) + ((a[j] >> 16) & 0xffu) + ((b[j] >> 8) & 0xffu) + ((b[j] >> 16) & 0xffu) + 2u;
-                packed |= (t >> 2) << (8 * j);
-            }
+            packed = box_px(v.x, u.x, 0x06050201u) | (box_px(v.y, u.y, 0x06050201u) << 8) |
+                     (box_px(v.z, u.z, 0x06050201u) << 16) | (box_px(v.w, u.w, 0x06050201u) << 24);
         } else {
+            // output pixel j: byte 3 of dword 2j and byte 0 of dword 2j + 1 of both rows
             const uint4 u0 = reinterpret_cast<const uint4*>(r0)[0], u1 = reinterpret_cast<const uint4*>(r0)[1];
             const uint4 v0 = reinterpret_cast<const uint4*>(r1)[0], v1 = reinterpret_cast<const uint4*>(r1)[1];
-            const uint32_t a[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-            const uint32_t b[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            packed = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t t = (a[2 * j] >> 24) + (a[2 * j + 1] & 0xffu) + (b[2 * j] >> 24) + (b[2 * j + 1] & 0xffu) + 2u;
-                packed |= (t >> 2) << (8 * j);
-            }
+            const uint32_t a0 = __builtin_amdgcn_perm(u0.y, u0.x, 0x0c0c0403u), b0 = __builtin_amdgcn_perm(v0.y, v0.x, 0x0c0c0403u);
+            const uint32_t a1 = __builtin_amdgcn_perm(u0.w, u0.z, 0x0c0c0403u), b1 = __builtin_amdgcn_perm(v0.w, v0.z, 0x0c0c0403u);
+            const uint32_t a2 = __builtin_amdgcn_perm(u1.y, u1.x, 0x0c0c0403u), b2 = __builtin_amdgcn_perm(v1.y, v1.x, 0x0c0c0403u);
+            const uint32_t a3 = __builtin_amdgcn_perm(u1.w, u1.z, 0x0c0c0403u), b3 = __builtin_amdgcn_perm(v1.w, v1.z, 0x0c0c0403u);
+            packed = box_px(b0, a0, 0x05040100u) | (box_px(b1, a1, 0x05040100u) << 8) |
+                     (box_px(b2, a2, 0x05040100u) << 16) | (box_px(b3, a3, 0x05040100u) << 24);
         }
         *reinterpret_cast<uint32_t*>(dst + (long long)(yb + row) * dpitch + xb + 4 * cg) = packed;
     }
