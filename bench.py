@@ -473,7 +473,7 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
     def go():
         capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), len(jobs), P(d_blob), blob.size, P(d_res)))
     # 31x31 templates: the lean walk kernel needs 11 KB of LDS per walk for the full-resolution level (include/slam_hip.h)
-    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 11520))     # 9 LDS granules of 1280 bytes: 14 walks per CU
+    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 10240))     # 8 LDS granules of 1280 bytes: 16 walks per CU
     go()
     torch.cuda.synchronize()
     res = d_res.cpu().numpy().view(TRACK_RES_DT)
@@ -512,7 +512,7 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
                                      "(area masks) on the coarsest level, stride 3; %d frames" % (w, h, nfeat, ts, ts, nfr),
                          "jobs": len(jobs), "pyramid_ms": ms_p, "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
                          "walked_all_levels": float((lr == 4).mean()), "jobs_left_to_general_kernel": deferred.value,
-                         "walk_lds_bytes": 11520, "parity": parity})
+                         "walk_lds_bytes": 10240, "parity": parity})
     capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 7680))      # back to the default
     pyr.close()
     return out

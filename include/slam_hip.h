@@ -60,7 +60,7 @@ int slam_hip_set_match_lds(slam_ctx* ctx, int bytes);
  * multiple of 64 in [4096, 65536], default 7680 (6 of the CU's 128 LDS granules of 1280 bytes: 21 walks share a
  * CU; only multiples of 1280 change that number).  A walk any of whose levels needs more - the image tile under the
  * window, the template's entry list and the score cells together - is left to the general kernel, so raise it for
- * templates beyond about 22x22 at full resolution (31x31 templates in 17x17 windows need 11520).  Results do not
+ * templates beyond about 22x22 at full resolution (31x31 templates in 17x17 windows need 10240: 16 walks per CU).  Results do not
  * depend on it. */
 int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes);
 /* Text of the last error on ctx (or of the last failed slam_hip_create when ctx is NULL). */

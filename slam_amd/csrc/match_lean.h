@@ -115,6 +115,16 @@ __device__ __forceinline__ LeanSlices lean_pick_slices(int nunits, int nA, int n
 // last slice, two past the masked part).
 __host__ __device__ __forceinline__ int lean_cap(int NG) { return NG + LEAN_MAX_S + 4; }
 
+// Entries of the mask array: only the masked part of the lists reads it.  A point walk's template mask is a warped
+// quadrilateral (feature.cpp:96-98): a row has at most two partly kept groups, and a last group cut by the template's
+// width, so the masked part holds at most 3 * th groups, the all-kept entries left over by the slicing (at most S - 1),
+// its padding (at most S - 1) and two entries read ahead.  A walk whose mask has more (noise) is turned away when its
+// lists are built and searched by the general kernel.  Single searches keep room for every group.
+__host__ __device__ __forceinline__ int lean_mcap(int NG, int th, bool walk) {
+    const int cap = lean_cap(NG), m = 3 * th + 2 * LEAN_MAX_S + 4;
+    return walk && NG > 32 && m < cap ? m : cap;           // templates of at most 32 groups mask every entry (lean_level)
+}
+
 // LDS bytes a level needs (INT_MAX: a shape this path does not take), with the window's column phase x0 & 3 at its
 // worst, so that the answer depends on sizes only and a walk can be turned away before its first level is searched.
 __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized) {
@@ -129,7 +139,7 @@ __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah
     const int raw_bytes = NG * 8 + (resized ? (G * 4 + th) * 8 : 0);
     // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
     if (tw > 256 || th > 256 || tw * th > 66051 || tp > 64 || nx * ny > 4096) return INT_MAX;
-    return ((nacc * 8 + 15) & ~15) + cap * 8 + ((cap * 4 + 15) & ~15) + (tile_bytes > raw_bytes ? tile_bytes : raw_bytes);
+    return ((nacc * 8 + 15) & ~15) + cap * 8 + ((lean_mcap(NG, th, true) * 4 + 15) & ~15) + (tile_bytes > raw_bytes ? tile_bytes : raw_bytes);
 }
 
 // accumulator index of the cell in tile column c (= o + x), row y, of a stride-1 search: strips of 4 columns run down
@@ -214,7 +224,7 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
         }
         {   // partly masked groups (and the padding entries, mask 0)
             const lds_u64* eb = list + nA1 + slice * nb;
-            const lds_u32* mb = marr + nA1 + slice * nb;
+            const lds_u32* mb = marr + slice * nb;          // marr: masks of the entries from nA1 on
             unsigned long long q0 = eb[0], q1 = eb[1];
             unsigned m0 = mb[0], m1 = mb[1];
             int e = 0;
@@ -262,7 +272,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int upr = strips ? cols : nx;                    // units per row
     const int cpu = strips ? 4 : 1;                        // cells per unit
     const int cap = lean_cap(NG);                          // room for the padding entries and for reads a few entries ahead
-    const int list_bytes = cap * 8, marr_bytes = (cap * 4 + 15) & ~15;
+    const int list_bytes = cap * 8, marr_bytes = (lean_mcap(NG, L.th, !SEARCH) * 4 + 15) & ~15;
     int bh = rows_all, nblk = 1;                           // unit rows per block, blocks
     if (!SEARCH) {
         if (lean_need(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized) > lds_total) { LEAN_REJECT(100); return out; }
@@ -287,7 +297,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int acc_bytes = (max(bh, min(3, rows_all)) * upr * cpu * 8 + 15) & ~15;
     lds_u32* acc = reinterpret_cast<lds_u32*>(lds);
     lds_u64* list = reinterpret_cast<lds_u64*>(lds + acc_bytes);
-    lds_u32* marr = reinterpret_cast<lds_u32*>(lds + acc_bytes + list_bytes);
+    lds_u32* marr = reinterpret_cast<lds_u32*>(lds + acc_bytes + list_bytes);       // masks of list entries nA1, nA1 + 1, ...: the all-kept part has none
     lds_u8* tile = lds + acc_bytes + list_bytes + marr_bytes;
     lds_u64* raw = reinterpret_cast<lds_u64*>(tile);       // {P0, M} per group in (row, group) order, until the tile is staged
     lds_u64* taps = raw + NG;
@@ -374,13 +384,15 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const LeanSlices lsl = lean_pick_slices(bh * upr, nA, nB, strips);
     const int S = lsl.S, na = lsl.na, nA1 = na * S;           // all-kept entries per slice; the rest of them joins the masked part
     const int nb = lsl.nb, nB1 = nb * S;
+    // a mask with more partly kept groups than a warped quadrilateral has (never true for single searches)
+    if (!SEARCH && nB1 + 2 > lean_mcap(NG, L.th, true)) { LEAN_REJECT(4); return out; }
     __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
     if (tiny) {                                             // every group a masked entry, in template order
         if (lane < NG) {
             const unsigned long long r = raw[lane];
             const int u = (int)(((float)lane + 0.5f) * rG), gq = lane - u * G;
             list[lane] = ((unsigned long long)((unsigned)(u * tp + gq) * 8u) << 32) | (unsigned)r;
-            marr[lane] = (unsigned)(r >> 32);
+            marr[lane] = (unsigned)(r >> 32);               // nA1 = 0 here
         }
         for (int p = NG + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p] = 0u; }
     } else {
@@ -395,11 +407,11 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             const unsigned long long en = ((unsigned long long)((unsigned)(u * tp + gq) * 8u) << 32) | P0;
             const unsigned long long below = (1ull << lane) - 1ull;
             // the raw region is read above and the lists written below live in different LDS ranges
-            if (isA) { const int p = baseA + __builtin_popcountll(ba & below); list[p] = en; marr[p] = M; }
-            if (isB) { const int p = baseB + __builtin_popcountll(bb & below); list[p] = en; marr[p] = M; }
+            if (isA) { const int p = baseA + __builtin_popcountll(ba & below); list[p] = en; if (p >= nA1) marr[p - nA1] = M; }
+            if (isB) { const int p = baseB + __builtin_popcountll(bb & below); list[p] = en; marr[p - nA1] = M; }
             baseA += __builtin_popcountll(ba); baseB += __builtin_popcountll(bb);
         }
-        for (int p = nA + nB + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p] = 0u; }   // padding: adds nothing
+        for (int p = nA + nB + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p - nA1] = 0u; }   // padding: adds nothing
     }
     STAMP(52);
 
