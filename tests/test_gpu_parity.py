@@ -220,7 +220,8 @@ def test_match_batches_take_the_lean_kernel_with_the_same_results(ctx, oracle):
                              stride=int(rng.integers(1, 5)), exact=bool(rng.integers(0, 2))))
         got = api.match_batch(ctx, pyr, jobs)
         left = api.debug_walk_deferred(ctx)
-        assert 0 < left < len(jobs) // 2, left                 # the border jobs, and few others
+        if os.environ.get("SLAM_HIP_NO_LEAN") != "1" and os.environ.get("SLAM_HIP_FORCE_DIRECT") != "1":   # cross-check runs skip the lean kernel
+            assert 0 < left < len(jobs) // 2, left             # the border jobs, and few others
         for k, (j, g) in enumerate(zip(jobs, got)):
             ref = oracle.match(frames[j["frame"]], j["patch"], j["patch_mask"], j["area"], j["area_mask"], j["stride"], j["exact"])
             assert g["status"] == 0
