@@ -410,6 +410,33 @@ def test_track_matches_oracle(ctx, oracle, w, h, subs, nfeat, tsize, min_found):
         pyr.close()
 
 
+def test_walks_with_noisy_masks_go_to_the_general_kernel(oracle):
+    """The lean walk kernel keeps mask-array room for the masks of warped quadrilaterals (at most three partly kept
+    groups per template row); a walk whose mask is noise is turned away when its lists are built and searched by the
+    general kernel - with the oracle's result either way."""
+    rng = np.random.default_rng(77 + SOAK_SEED)
+    w, h, subs, shift = 640, 480, [1, 2, 4], (3, -2)
+    f0, f1 = synth.frame(w, h, 21), synth.frame(w, h, 21, shift)
+    jobs = _c2_like_jobs(rng, w, h, 16, 21, f0, shift)
+    for k, j in enumerate(jobs):
+        if k % 2:
+            j["proj_mask"] = (rng.random(j["proj"].shape) < 0.5).astype(np.uint8)      # noise: every group partly kept
+    with api.Context(0) as c:
+        pyr = api.ImagePyramid(c, f1, subs)
+        try:
+            got = api.track_batch(c, pyr, jobs)
+            left = api.debug_walk_deferred(c)
+        finally:
+            pyr.close()
+    if os.environ.get("SLAM_HIP_NO_LEAN") != "1" and os.environ.get("SLAM_HIP_FORCE_DIRECT") != "1":
+        assert left == len(jobs) // 2, left
+    levels = oracle.pyramid(f1, subs)
+    for j, g in zip(jobs, got):
+        r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+        assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"])
+        assert _same_float(g["response"], r["response"]) and _same_float(g["dx"], r["dx"]) and _same_float(g["dy"], r["dy"])
+
+
 @pytest.mark.parametrize("lds", [4096, 7680, 8192, 9664, 12800, 32768, 64512])
 def test_results_do_not_depend_on_the_lds_budget(oracle, lds):
     """The LDS a job may use only changes how its work is cut into blocks and chunks (slam_hip_set_match_lds):
