@@ -34,3 +34,9 @@ def ctx():
 # Added to the seeds of the randomised differential tests (SLAM_TEST_SEED=n python -m pytest ...): other inputs,
 # same checks - for soak runs beyond the default stream.
 SOAK_SEED = int(os.environ.get("SLAM_TEST_SEED", "0"))
+
+# True when no environment knob moves work between the lean and the general kernels.  Assertions about which kernel took
+# how many jobs hold for the default split only; the parity assertions hold under every knob.
+DEFAULT_KERNEL_SPLIT = not any(os.environ.get(k) for k in (
+    "SLAM_HIP_NO_LEAN", "SLAM_HIP_FORCE_DIRECT", "SLAM_HIP_WALK_LDS_BYTES", "SLAM_HIP_WALK_LDS_KB",
+    "SLAM_HIP_SEARCH_LDS_BYTES", "SLAM_HIP_SEARCH_LDS_KB", "SLAM_HIP_MATCH_LDS_KB", "SLAM_HIP_SEARCH_LEAN_MIN"))

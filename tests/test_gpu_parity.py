@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SOAK_SEED
+from conftest import DEFAULT_KERNEL_SPLIT, SOAK_SEED
 
 from slam_amd import api, synth
 
@@ -220,7 +220,7 @@ def test_match_batches_take_the_lean_kernel_with_the_same_results(ctx, oracle):
                              stride=int(rng.integers(1, 5)), exact=bool(rng.integers(0, 2))))
         got = api.match_batch(ctx, pyr, jobs)
         left = api.debug_walk_deferred(ctx)
-        if os.environ.get("SLAM_HIP_NO_LEAN") != "1" and os.environ.get("SLAM_HIP_FORCE_DIRECT") != "1":   # cross-check runs skip the lean kernel
+        if DEFAULT_KERNEL_SPLIT:   # cross-check runs skip the lean kernel
             assert 0 < left < len(jobs) // 2, left             # the border jobs, and few others
         for k, (j, g) in enumerate(zip(jobs, got)):
             ref = oracle.match(frames[j["frame"]], j["patch"], j["patch_mask"], j["area"], j["area_mask"], j["stride"], j["exact"])
@@ -428,7 +428,7 @@ def test_walks_with_noisy_masks_go_to_the_general_kernel(oracle):
             left = api.debug_walk_deferred(c)
         finally:
             pyr.close()
-    if os.environ.get("SLAM_HIP_NO_LEAN") != "1" and os.environ.get("SLAM_HIP_FORCE_DIRECT") != "1":
+    if DEFAULT_KERNEL_SPLIT:
         assert left == len(jobs) // 2, left
     levels = oracle.pyramid(f1, subs)
     for j, g in zip(jobs, got):
@@ -787,7 +787,8 @@ def test_c3_track_walk_with_ellipse_windows(ctx, oracle):
         got = api.track_batch(ctx, pyr, jobs)
         # the entry point saw the shapes on the host and sized the lean walk kernel for them: only walks that leave
         # the image, are cropped by it or find nothing to visit are left to the general kernel (all of them without sizing)
-        assert api.debug_walk_deferred(ctx) <= len(jobs) // 4
+        if DEFAULT_KERNEL_SPLIT:
+            assert api.debug_walk_deferred(ctx) <= len(jobs) // 4
     finally:
         pyr.close()
     levels = oracle.pyramid(f1, subs)

@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import DEFAULT_KERNEL_SPLIT
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -52,7 +54,7 @@ def test_noalloc_walk_equals_the_allocating_entry_point_twice_in_a_row():
             capi.check(ctx.handle, L.slam_hip_debug_walk_deferred(ctx.handle, C.byref(deferred)))
             got = _run(L.slam_hip_track_batch_noalloc_d, ctx, pyr, jobs, blob)
             assert (want["status"] == 0).all() and (want["levels_run"] >= 1).all()
-            if os.environ.get("SLAM_HIP_NO_LEAN") != "1" and os.environ.get("SLAM_HIP_FORCE_DIRECT") != "1":   # cross-check runs skip the lean kernel
+            if DEFAULT_KERNEL_SPLIT:   # cross-check runs skip the lean kernel
                 assert 0 < deferred.value < len(jobs)    # both kernels had work: the queue was really used
             assert np.array_equal(got, want), (nseq, np.flatnonzero(got != want)[:8])
             pyr.close()
