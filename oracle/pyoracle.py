@@ -4,6 +4,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 All image arguments are C-contiguous uint8 numpy arrays (rows = height).
 """
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -15,11 +16,15 @@ _lib = None
 
 
 def build(force=False):
-    """Compile the oracle with gcc (seconds)."""
+    """Compile the oracle with gcc (seconds).  Safe when several processes call it at once (the ranks of a multi-GPU
+    bench): the check and the build run under a file lock, so one process builds and the others find the result."""
     src = [os.path.join(_HERE, f) for f in ("slam_oracle.c", "slam_oracle.h", "Makefile")]
-    if force or not os.path.exists(_SO) or any(
-            os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    with open(os.path.join(os.path.dirname(_SO), ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not os.path.exists(_SO) or any(
+                os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
 
 
