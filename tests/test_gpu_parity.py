@@ -45,6 +45,27 @@ def _check_match(ctx, oracle, im, patch, pm, area, am, stride, exact=False):
     return ref, got
 
 
+def test_wide_templates_without_a_patch_mask(ctx, oracle):
+    """Templates of 7 groups of 4 pixels and more without a patch mask: the general kernel sums the window energy of a
+    strip's first cell and slides it to the other three.  Widths around the group boundaries, windows inside the image
+    and over its borders, with and without an area mask, full score maps compared."""
+    rng = np.random.default_rng(8100 + SOAK_SEED)
+    small = [(25, 9), (28, 7), (29, 12), (32, 5), (33, 33), (40, 40), (81, 81), (130, 6), (257, 3)]
+    for W, H, sizes in ((320, 240, small), (640, 480, [(300, 230)])):      # 300 x 230: sums beyond 32 bits
+        im = synth.frame(W, H, 81 + SOAK_SEED)
+        flat = np.full((H, W), 255, np.uint8)               # the largest sums the window energy can reach
+        for tw, th in sizes:
+            for k in range(3):
+                src = flat if k == 2 else im
+                x0, y0 = int(rng.integers(0, W - tw)), int(rng.integers(0, H - th))
+                patch = np.ascontiguousarray(src[y0:y0 + th, x0:x0 + tw]) if k else rng.integers(0, 256, (th, tw), dtype=np.uint8)
+                aw, ah = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+                ax = int(rng.integers(-6, W - aw + 6)) if k == 1 else int(rng.integers(tw // 2, W - tw // 2 - aw))
+                ay = int(rng.integers(-6, H - ah + 6)) if k == 1 else int(rng.integers(th // 2, H - th // 2 - ah))
+                am = (rng.random((ah, aw)) < 0.7).astype(np.uint8) if rng.random() < 0.5 else None
+                _check_match(ctx, oracle, src, patch, None, (ax, ay, aw, ah), am, int(rng.integers(1, 4)), exact=bool(rng.random() < 0.5))
+
+
 def test_score_formulas_bit_exact(ctx):
     rng = np.random.default_rng(1)
     n = 200000
