@@ -50,7 +50,7 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     const char* wk = getenv("SLAM_HIP_WALK_LDS_KB");
     if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) { c->lean_lds_bytes = atoi(wk) * 1024; c->lean_lds_user = 1; }
     const char* wb = getenv("SLAM_HIP_WALK_LDS_BYTES");
-    if (wb && atoi(wb) >= 4096 && atoi(wb) <= 65536) { c->lean_lds_bytes = atoi(wb) & ~255; c->lean_lds_user = 1; }
+    if (wb && atoi(wb) >= 4096 && atoi(wb) <= 65536) { c->lean_lds_bytes = atoi(wb) & ~63; c->lean_lds_user = 1; }
     const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");
     if (sk && atoi(sk) >= 4 && atoi(sk) <= 64) c->lean_match_lds_bytes = atoi(sk) * 1024;
     const char* sb = getenv("SLAM_HIP_SEARCH_LDS_BYTES");
@@ -86,7 +86,12 @@ extern "C" int slam_hip_destroy(slam_ctx* ctx) {
 
 extern "C" int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream) {
     if (!ctx) return SLAM_HIP_EINVAL;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next == ctx->stream) return SLAM_HIP_OK;
+    // the context's queue, staging and pinned buffers are ordered by one stream: work on the old one ends first
+    SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = next;
     return SLAM_HIP_OK;
 }
 
@@ -216,8 +221,8 @@ int slam_queue_reserve(slam_ctx* ctx, int njobs) {
         return slam_set_error(ctx, SLAM_HIP_ENOMEM, "walk queue hipMalloc(%zu words): %s", want + 16, hipGetErrorString(e));
     }
     ctx->queue_jobs = want;
-    ctx->queue_cnt = 0; ctx->queue_last = 0;
-    SLAM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 16 * sizeof(int), ctx->stream));     // both counters start at zero
+    ctx->queue_last = 0;
+    SLAM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 16 * sizeof(int), ctx->stream));     // the counters start at zero; every launch leaves them so
     return SLAM_HIP_OK;
 }
 

@@ -722,6 +722,36 @@ extern "C" int slam_hip_fast_detect(slam_ctx* ctx, const uint8_t* h_frames, int 
                                 threshold, nonmax, out, cap_per_frame, counts);
 }
 
+// One FAST pass over the resident image followed by the device sort (new_point.cpp:120,124): the frame's corners,
+// sorted by response descending (ties y, x ascending), arrive in kps; *found = their number.
+static int fast_sorted_resident(slam_ctx* ctx, const uint8_t* d_frame, int w, int h, size_t dpitch, size_t dstride,
+                                int threshold, std::vector<slam_keypoint>& kps, size_t* found) {
+    const int cap = (int)kps.size();
+    const size_t sb = slam_hip_fast_scratch_bytes(w, h, 1, cap);
+    if (!sb) return slam_set_error(ctx, SLAM_HIP_EINVAL, "get_sorted_keypoints: unsupported shape %dx%d", w, h);
+    const size_t ob = sizeof(slam_keypoint) * (size_t)cap;          // slot 2: the row-major list, then the sorted one
+    int rc;
+    if ((rc = slam_stage_reserve(ctx, 1, sb)) || (rc = slam_stage_reserve(ctx, 2, 2 * ob)) || (rc = slam_stage_reserve(ctx, 3, 4)))
+        return rc;
+    slam_keypoint* d_list = (slam_keypoint*)ctx->d_stage[2];
+    slam_keypoint* d_sorted = d_list + cap;
+    rc = slam_hip_fast_detect_d(ctx, d_frame, w, h, dpitch, dstride, 1, threshold, 1, d_list, cap, (int32_t*)ctx->d_stage[3],
+                                ctx->d_stage[1], ctx->stage_bytes[1]);
+    if (rc != SLAM_HIP_OK) return rc;
+    rc = slam_hip_sort_keypoints_d(ctx, d_list, (const int32_t*)ctx->d_stage[3], 1, cap, d_sorted);
+    if (rc != SLAM_HIP_OK) return rc;
+    int32_t cnt = 0;
+    SLAM_HIP_CHECK(ctx, hipMemcpyAsync(&cnt, ctx->d_stage[3], 4, hipMemcpyDeviceToHost, ctx->stream));
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (cnt > cap) return slam_set_error(ctx, SLAM_HIP_ECAP, "get_sorted_keypoints: %d corners, room for %d", cnt, cap);
+    if (cnt > 0) {
+        SLAM_HIP_CHECK(ctx, hipMemcpyAsync(kps.data(), d_sorted, sizeof(slam_keypoint) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream));
+        SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *found = (size_t)cnt;
+    return SLAM_HIP_OK;
+}
+
 extern "C" int slam_hip_get_sorted_keypoints(slam_ctx* ctx, const uint8_t* im, int w, int h, size_t pitch,
                                              size_t n_min_pts, float* fast_threshold,
                                              slam_keypoint* out, int cap, int32_t* n_out) {
@@ -730,54 +760,43 @@ extern "C" int slam_hip_get_sorted_keypoints(slam_ctx* ctx, const uint8_t* im, i
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "get_sorted_keypoints: bad arguments");
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     slam_stream_drain drain(ctx);        // error returns below wait for the copies queued so far
-    size_t dpitch, dstride;
-    int rc = fast_upload(ctx, im, w, h, pitch, pitch * (size_t)h, 1, dpitch, dstride);
-    if (rc != SLAM_HIP_OK) return rc;
-    // non-max-suppressed corners are never 8-adjacent: at most ceil(w/2)*ceil(h/2) of them
-    const size_t kmax = (size_t)((w + 1) / 2) * (size_t)((h + 1) / 2);
-    std::vector<slam_keypoint> kps(kmax ? kmax : 1);
     float f = *fast_threshold;
     size_t n = 0;
+    std::vector<slam_keypoint> kps;
     // new_point.cpp:116-122: while (out.size() < nMinPts) { FAST(im, out, fastThreshold, true); fastThreshold *= .5; }
-    // The first pass runs at the current threshold and usually ends the loop.  When it does not, ONE more pass at
-    // threshold 0 serves every later iteration: a corner's score does not depend on the threshold it was detected
-    // with, and a pixel survives non-max suppression at threshold t >= 1 exactly when it survives at threshold 0 and
-    // its score is at least t (a neighbour that is no corner at t scores below t, hence below the pixel), so the
-    // list of iteration t is the threshold-0 list, in its row-major order, without the scores below t.
-    {
-        const int t = (int)f;                                 // FAST(im, out, fastThreshold, true): float -> int
-        int32_t cnt = 0;
-        rc = fast_detect_resident(ctx, (const uint8_t*)ctx->d_stage[0], w, h, dpitch, dstride, 1, t, 1,
-                                  kps.data(), (int)kps.size(), &cnt);
+    // With nMinPts == 0 the loop body never runs: no keypoints, and the threshold is only doubled below.
+    if (n_min_pts > 0) {
+        size_t dpitch, dstride;
+        int rc = fast_upload(ctx, im, w, h, pitch, pitch * (size_t)h, 1, dpitch, dstride);
         if (rc != SLAM_HIP_OK) return rc;
-        n = (size_t)cnt;
+        // non-max-suppressed corners are never 8-adjacent: at most ceil(w/2)*ceil(h/2) of them
+        const size_t kmax = (size_t)((w + 1) / 2) * (size_t)((h + 1) / 2);
+        kps.resize(kmax ? kmax : 1);
+        // The first pass runs at the current threshold and usually ends the loop.  When it does not, ONE more pass at
+        // threshold 0 serves every later iteration: a corner's score does not depend on the threshold it was detected
+        // with, and a pixel survives non-max suppression at threshold t >= 1 exactly when it survives at threshold 0 and
+        // its score is at least t (a neighbour that is no corner at t scores below t, hence below the pixel), so the
+        // list of iteration t is the threshold-0 list without the scores below t - and, both being sorted by
+        // (response descending, y, x) on the device (new_point.cpp:124 sorts by response only with an unstable sort;
+        // ties are fixed as y, x ascending), a prefix of it.
+        const int t = (int)f;                                 // FAST(im, out, fastThreshold, true): float -> int
+        rc = fast_sorted_resident(ctx, (const uint8_t*)ctx->d_stage[0], w, h, dpitch, dstride, t, kps, &n);
+        if (rc != SLAM_HIP_OK) return rc;
         f *= 0.5f;
         if (n < n_min_pts && t > 0) {       // the reference never leaves this loop on a corner-poor image; here it stops after t = 0
-            rc = fast_detect_resident(ctx, (const uint8_t*)ctx->d_stage[0], w, h, dpitch, dstride, 1, 0, 1,
-                                      kps.data(), (int)kps.size(), &cnt);
+            size_t n0 = 0;
+            rc = fast_sorted_resident(ctx, (const uint8_t*)ctx->d_stage[0], w, h, dpitch, dstride, 0, kps, &n0);
             if (rc != SLAM_HIP_OK) return rc;
-            const size_t n0 = (size_t)cnt;
             for (;;) {
                 const int ti = (int)f;
-                n = 0;
-                for (size_t i = 0; i < n0; i++) n += kps[i].response >= (float)ti;
+                // keypoints with response >= ti: a prefix of the descending list
+                n = (size_t)(std::partition_point(kps.begin(), kps.begin() + n0, [ti](const slam_keypoint& k) { return k.response >= (float)ti; }) - kps.begin());
                 f *= 0.5f;
-                if (n >= n_min_pts || ti <= 0) {
-                    size_t k = 0;
-                    for (size_t i = 0; i < n0; i++)
-                        if (kps[i].response >= (float)ti) kps[k++] = kps[i];
-                    break;
-                }
+                if (n >= n_min_pts || ti <= 0) break;
             }
         }
     }
     f *= 2.f;                                                 // new_point.cpp:123
-    // new_point.cpp:124 sorts by response only with an unstable sort; ties are fixed as y, x ascending
-    std::sort(kps.begin(), kps.begin() + n, [](const slam_keypoint& a, const slam_keypoint& b) {
-        if (a.response != b.response) return a.response > b.response;
-        if (a.y != b.y) return a.y < b.y;
-        return a.x < b.x;
-    });
     if (n > 2 * n_min_pts) f = kps[(size_t)((double)n_min_pts * 1.9)].response;   // new_point.cpp:125-126
     *fast_threshold = f;
     *n_out = (int32_t)n;

@@ -5,6 +5,7 @@
 //                   on the previous level's result)
 #include <cfloat>
 #include <climits>
+#include <mutex>
 
 #include "match_lean.h"
 
@@ -224,6 +225,23 @@ __device__ __forceinline__ void match_job(const slam_pyr_dev& pyr, const slam_ma
 
 #define SLAM_DEFER_LIST 16
 
+// Queue of the jobs a lean kernel leaves to the general one.  Word 0 counts them, word 1 counts the workgroups of the
+// general kernel that are done, word 2 keeps the count of the last launch (diagnostics); the job indices start at word
+// SLAM_DEFER_LIST.  Every launch leaves words 0 and 1 at zero: the workgroup that finishes last clears them, after every
+// other one has read the count, so a launch depends on no host-side state and a captured launch replays as often as
+// wanted.  Wave-uniform caller.
+__device__ __forceinline__ void queue_done(int* queue, int count) {
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(queue + 1, 1) == (int)gridDim.x - 1) {
+            queue[2] = count;
+            queue[0] = 0;
+            queue[1] = 0;
+            __threadfence();
+        }
+    }
+}
+
 // General single-search kernel.  queue == nullptr: workgroup b takes job b.  Otherwise the workgroups share out the jobs
 // the lean kernel queued (a later launch on the same stream: its counter and list are complete and visible).
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
                                                         unsigned long long blob_bytes, float* scores,
                                                         unsigned long long scores_len,
                                                         slam_match_result* __restrict__ out, int force_direct, int lds_total,
-                                                        int* __restrict__ queue, int cnt) {
+                                                        int* queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     const LdsPlan plan = make_lds_plan(lds_total);
@@ -240,15 +258,13 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
         if (j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
         return;
     }
-    // The queue has two counters, used by alternate launches: this launch reads word `cnt` and clears the other one
-    // for the lean kernel of the next launch (which starts after this kernel has ended), so no launch needs a memset.
-    if (blockIdx.x == 0 && threadIdx.x == 0) queue[cnt ^ 8] = 0;
-    const int count = min(queue[cnt], njobs);
+    const int count = min(__builtin_amdgcn_readfirstlane(queue[0]), njobs);
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const int j = queue[SLAM_DEFER_LIST + q];
         __syncthreads();                                   // the previous job's last readers of the dynamic LDS
         if (j >= 0 && j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
     }
+    queue_done(queue, count);
 }
 
 // Lean single-search kernel: one matchFeatureInArea call whose candidate patches all lie inside the image, without a
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LEAN_SEARCH) void match_lean_kernel(slam_pyr_dev pyr, const slam_match_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes, const float* scores,
-                                                        slam_match_result* __restrict__ out, int lds_total, int* __restrict__ queue, int cnt) {
+                                                        slam_match_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     const int j = blockIdx.x;
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LEAN_SEARCH) void match_lea
     }
     if (threadIdx.x == 0) {
         if (o.ok) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
-        else queue[SLAM_DEFER_LIST + atomicAdd(queue + cnt, 1)] = j;
+        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
     }
 }
 
@@ -438,14 +454,13 @@ __device__ __forceinline__ void track_job(const slam_pyr_dev& pyr, const slam_tr
     }
 }
 
-// Queue of jobs the lean kernel left to the general one: word 0 counts them, the job indices start at word 16.
 // General walk kernel.  queue == nullptr: workgroup b walks job b.  Otherwise the workgroups share out the jobs the
 // lean kernel queued (a later launch on the same stream: its counter and list are complete and visible).
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
                                                         slam_track_result* __restrict__ out, int force_direct, int lds_total,
-                                                        int* __restrict__ queue, int cnt) {
+                                                        int* queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ TrackLevel lc[SLAM_HIP_MAX_LEVELS];
     lds_u8* lds = (lds_u8*)dyn_lds;
@@ -455,13 +470,13 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
         return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) queue[cnt ^ 8] = 0;      // the other counter, for the next launch (see match_kernel)
-    const int count = min(queue[cnt], njobs);
+    const int count = min(__builtin_amdgcn_readfirstlane(queue[0]), njobs);
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const int j = queue[SLAM_DEFER_LIST + q];
         __syncthreads();                                   // the previous job's last readers of lc and the dynamic LDS
         if (j >= 0 && j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
     }
+    queue_done(queue, count);                              // see match_kernel
 }
 
 // Lean walk kernel: the level loop of SLAM::Feature::track (feature.cpp:117-172) for walks whose every level is an
@@ -580,7 +595,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
-                                                        slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue, int cnt) {
+                                                        slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own.  Workgroup b takes job
@@ -595,7 +610,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(sla
     const bool done = lean_walk(pyr, job, blob, blob_bytes, lds, lds_total, r);
     if (threadIdx.x == 0) {
         if (done) out[j] = r;
-        else queue[SLAM_DEFER_LIST + atomicAdd(queue + cnt, 1)] = j;
+        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
     }
 }
 
@@ -704,6 +719,14 @@ __global__ void score_formula_kernel(const unsigned long long* cc, const unsigne
     mto[i] = score_mt(cc[i], si[i], sp[i]);
 }
 
+// After the launch of the general kernel behind a lean one.  The general kernel is what returns the queue's counters to
+// zero; if it could not be launched the lean kernel's count would stay behind, so the counters are cleared here.
+int slam_queue_launched(slam_ctx* ctx, int* queue, hipError_t e) {
+    if (e == hipSuccess) return SLAM_HIP_OK;
+    (void)hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream);
+    return slam_set_error(ctx, SLAM_HIP_EHIP, "launch of the general kernel failed: %s", hipGetErrorString(e));
+}
+
 int check_pyr(slam_ctx* ctx, const slam_pyr* pyr, const char* who) {
     if (!pyr || !pyr->built) return slam_set_error(ctx, SLAM_HIP_EINVAL, "%s: pyramid not built", who);
     if (pyr->device != ctx->device) return slam_set_error(ctx, SLAM_HIP_EINVAL, "%s: pyramid belongs to device %d", who, pyr->device);
@@ -720,10 +743,12 @@ static __device__ __align__(256) int g_walk_scratch[SLAM_DEFER_LIST + SLAM_NOALL
 
 #define SLAM_MAX_DEVICES 64
 static int* g_walk_scratch_ptr[SLAM_MAX_DEVICES] = {nullptr};
+static std::mutex g_walk_scratch_mutex;      // contexts are created from several host threads (one per thread and device)
 
 // Called by slam_hip_create with the context's device current.
 int slam_track_scratch_init(slam_ctx* ctx) {
     if (ctx->device < 0 || ctx->device >= SLAM_MAX_DEVICES) return SLAM_HIP_OK;      // such a device simply has no no-alloc entry point
+    std::lock_guard<std::mutex> lock(g_walk_scratch_mutex);
     if (g_walk_scratch_ptr[ctx->device]) return SLAM_HIP_OK;
     void* p = nullptr;
     const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_walk_scratch));
@@ -756,26 +781,23 @@ extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (ctx->force_direct || ctx->no_lean || njobs < ctx->lean_match_min_jobs) {
         hipLaunchKernelGGL(match_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
                            pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
-                           (unsigned long long)scores_len, d_out, ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr, 0);
+                           (unsigned long long)scores_len, d_out, ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr);
         SLAM_HIP_CHECK(ctx, hipGetLastError());
         return SLAM_HIP_OK;
     }
     rc = slam_queue_reserve(ctx, njobs);
     if (rc != SLAM_HIP_OK) return rc;
     int* queue = ctx->d_queue;
-    const int cnt = ctx->queue_cnt;                        // this launch's counter; the general kernel clears the other one
-    ctx->queue_cnt ^= 8;
-    ctx->queue_last = cnt;
+    ctx->queue_last = 0;
     hipLaunchKernelGGL(match_lean_kernel, dim3(njobs), dim3(SLAM_WG), ctx->lean_match_lds_bytes, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, (const float*)d_scores, d_out,
-                       ctx->lean_match_lds_bytes, queue, cnt);
-    SLAM_HIP_CHECK(ctx, hipGetLastError());
+                       ctx->lean_match_lds_bytes, queue);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());                // nothing was queued: the counters are still zero
     const int grid = njobs < 4096 ? njobs : 4096;
     hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
-                       (unsigned long long)scores_len, d_out, 0, ctx->match_lds_bytes, queue, cnt);
-    SLAM_HIP_CHECK(ctx, hipGetLastError());
-    return SLAM_HIP_OK;
+                       (unsigned long long)scores_len, d_out, 0, ctx->match_lds_bytes, queue);
+    return slam_queue_launched(ctx, queue, hipGetLastError());
 }
 
 static int mask_is_01(const uint8_t* m, size_t n) {
@@ -881,16 +903,14 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
         ctx->lean_lds_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                           ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr, 0);
+                           ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr);
         SLAM_HIP_CHECK(ctx, hipGetLastError());
         return SLAM_HIP_OK;
     }
     int rc2 = slam_queue_reserve(ctx, njobs);
-    if (rc2 != SLAM_HIP_OK) return rc2;
-    const int cnt = ctx->queue_cnt;                        // this launch's counter; the general kernel clears the other one
-    ctx->queue_cnt ^= 8;
-    ctx->queue_last = cnt;
-    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, ctx->d_queue, cnt);
+    if (rc2 != SLAM_HIP_OK) { ctx->lean_lds_once = 0; return rc2; }
+    ctx->queue_last = 0;
+    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, ctx->d_queue, false);
 }
 
 // The entry points that take their job table from the host see the shapes before the launch: they size the lean walk
@@ -930,24 +950,21 @@ void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job
 // Lean kernel over all jobs, then the general kernel over whatever it queued.  `queue`: device words, SLAM_DEFER_LIST
 // + njobs of them.  Allocates nothing.
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
-                      size_t blob_bytes, slam_track_result* d_out, int* queue, int cnt) {
+                      size_t blob_bytes, slam_track_result* d_out, int* queue, bool clear_first) {
     const int lds = ctx->lean_lds_once ? ctx->lean_lds_once : ctx->lean_lds_bytes;      // a host-table entry point may have sized this launch
     ctx->lean_lds_once = 0;
-    // cnt < 0: a queue shared by every context of the device (the no-alloc entry point): cleared here, counter 0
-    if (cnt < 0) {
-        SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
-        cnt = 0;
-    }
+    // a queue shared by every context of the device (the no-alloc entry point) is cleared first: another context's
+    // failed launch must not leave its count behind
+    if (clear_first) SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(track_lean_kernel, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), lds, ctx->stream, pyr->dev, d_jobs, njobs,
-                       d_blob, (unsigned long long)blob_bytes, d_out, lds, queue, cnt);
-    SLAM_HIP_CHECK(ctx, hipGetLastError());
+                       d_blob, (unsigned long long)blob_bytes, d_out, lds, queue);
+    SLAM_HIP_CHECK(ctx, hipGetLastError());                // nothing was queued: the counters are still zero
     // enough workgroups to fill the chip if everything was queued, few enough to start and end in microseconds if nothing was
     const int grid = njobs < 4096 ? njobs : 4096;
     hipLaunchKernelGGL(track_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                       0, ctx->match_lds_bytes, queue, cnt);
-    SLAM_HIP_CHECK(ctx, hipGetLastError());
-    return SLAM_HIP_OK;
+                       0, ctx->match_lds_bytes, queue);
+    return slam_queue_launched(ctx, queue, hipGetLastError());
 }
 
 extern "C" int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs,
@@ -968,12 +985,12 @@ extern "C" int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr
         ctx->lean_lds_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                           ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr, 0);
+                           ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr);
         SLAM_HIP_CHECK(ctx, hipGetLastError());
         return SLAM_HIP_OK;
     }
     ctx->queue_last = -1;
-    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, q, -1);
+    return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, q, true);
 }
 
 extern "C" int slam_hip_track_batch(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs,
@@ -1055,11 +1072,11 @@ extern "C" int slam_hip_debug_walk_deferred(slam_ctx* ctx, int* out_deferred) {
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->force_direct || ctx->no_lean) return SLAM_HIP_OK;
-    const int* counter = nullptr;                           // of the context's last launch with a queue
-    if (ctx->queue_last >= 0) counter = ctx->d_queue ? ctx->d_queue + ctx->queue_last : nullptr;
-    else if (ctx->device >= 0 && ctx->device < SLAM_MAX_DEVICES) counter = g_walk_scratch_ptr[ctx->device];
-    if (!counter) return SLAM_HIP_OK;
-    SLAM_HIP_CHECK(ctx, hipMemcpy(out_deferred, counter, sizeof(int), hipMemcpyDeviceToHost));
+    const int* queue = nullptr;                             // of the context's last launch with a queue
+    if (ctx->queue_last >= 0) queue = ctx->d_queue;
+    else if (ctx->device >= 0 && ctx->device < SLAM_MAX_DEVICES) queue = g_walk_scratch_ptr[ctx->device];
+    if (!queue) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipMemcpy(out_deferred, queue + 2, sizeof(int), hipMemcpyDeviceToHost));   // word 2: the last launch's count
     return SLAM_HIP_OK;
 }
 

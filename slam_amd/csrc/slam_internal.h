@@ -31,10 +31,9 @@ struct slam_ctx {
     int lean_match_lds_bytes = 7680;   // LDS per job of the lean single-search kernel: 6 granules; its registers allow 20 jobs per CU (SLAM_HIP_SEARCH_LDS_KB / _BYTES)
     int lean_match_min_jobs = 64;      // smaller batches of single searches take the general kernel alone (SLAM_HIP_SEARCH_LEAN_MIN)
     // queue of walk jobs the lean kernel leaves to the general one: a counter word, then the job indices
-    int* d_queue = nullptr;            // 16 words (two counters: words 0 and 8), then the list of queued job indices
+    int* d_queue = nullptr;            // 16 words (count, workgroups done, last launch's count), then the list of queued job indices
     size_t queue_jobs = 0;
-    int queue_cnt = 0;                 // counter word of the next launch (0 / 8 alternating; the other one is zero by then)
-    int queue_last = 0;                // counter word of the last launch, -1: it used the device's no-alloc scratch
+    int queue_last = 0;                // queue of the last launch: 0 = d_queue, -1 = the device's no-alloc scratch
     // one-level pyramid reused by slam_hip_match_feature_in_area while the image size stays the same
     slam_pyr* mfa_pyr = nullptr;
     int mfa_w = 0, mfa_h = 0;
@@ -104,10 +103,9 @@ int slam_upload_image(slam_ctx* ctx, uint8_t* d_dst, size_t dpitch, const uint8_
                       size_t slot_off);
 int slam_track_scratch_init(slam_ctx* ctx);
 void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs);
-// cnt: word of the queue's counter this launch uses (0 or 8, alternating: see match_kernel), or -1 for a queue that
-// is cleared by a memset first
+// clear_first: clear the queue's counters with a memset before the launch (a queue several contexts share)
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
-                      size_t blob_bytes, slam_track_result* d_out, int* queue, int cnt);
+                      size_t blob_bytes, slam_track_result* d_out, int* queue, bool clear_first);
 
 #define SLAM_HIP_CHECK(ctx, call)                                                              \
     do {                                                                                       \

@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Some GPU tests drive the library from torch streams and graphs.  torch ships a HIP runtime of its own: when it
+    initialises after libslam_hip.so has brought up the system one it finds no device, so on a GPU box torch goes first."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure): compiled on demand with gcc."""

@@ -591,12 +591,16 @@ def test_fast_capacity_is_reported(ctx, oracle):
 
 
 def test_get_sorted_keypoints_matches_oracle(ctx, oracle):
-    for (w, h, nmin, f0) in [(640, 480, 100, 10.0), (320, 240, 100, 200.0), (320, 240, 5, 10.0), (64, 64, 100000, 10.0)]:
+    # nmin = 0: the loop of new_point.cpp:116-122 is never entered - no keypoints, the threshold doubled (:123)
+    for (w, h, nmin, f0) in [(640, 480, 100, 10.0), (320, 240, 100, 200.0), (320, 240, 5, 10.0), (64, 64, 100000, 10.0),
+                             (320, 240, 0, 10.0), (64, 64, 0, 0.75)]:
         im = synth.frame(w, h, 33)
         ref, fref = oracle.get_sorted_keypoints(im, nmin, f0)
         got, fgot = api.get_sorted_keypoints(ctx, im, nmin, f0)
         assert fgot == fref
-        assert _kp_set(got) == _kp_set(ref)
+        assert np.array_equal(got, ref)
+        if nmin == 0:
+            assert len(got) == 0 and fgot == np.float32(f0) * 2
     # an image without corners terminates (the reference would not) and returns nothing
     got, fgot = api.get_sorted_keypoints(ctx, np.full((40, 40), 9, np.uint8), 10, 10.0)
     assert len(got) == 0
