@@ -222,7 +222,7 @@ int slam_queue_reserve(slam_ctx* ctx, int njobs) {
     }
     ctx->queue_jobs = want;
     ctx->queue_last = 0;
-    SLAM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, 16 * sizeof(int), ctx->stream));     // the counters start at zero; every launch leaves them so
+    SLAM_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_queue, 0, (want + 16) * sizeof(int), ctx->stream));     // counter and list start at zero; every launch leaves them so
     return SLAM_HIP_OK;
 }
 

@@ -225,22 +225,23 @@ __device__ __forceinline__ void match_job(const slam_pyr_dev& pyr, const slam_ma
 
 #define SLAM_DEFER_LIST 16
 
-// Queue of the jobs a lean kernel leaves to the general one.  Word 0 counts them, word 1 counts the workgroups of the
-// general kernel that are done, word 2 keeps the count of the last launch (diagnostics); the job indices start at word
-// SLAM_DEFER_LIST.  Every launch leaves words 0 and 1 at zero: the workgroup that finishes last clears them, after every
-// other one has read the count, so a launch depends on no host-side state and a captured launch replays as often as
-// wanted.  Wave-uniform caller.
-__device__ __forceinline__ void queue_done(int* queue, int count) {
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(queue + 1, 1) == (int)gridDim.x - 1) {
-            queue[2] = count;
-            queue[0] = 0;
-            queue[1] = 0;
-            __threadfence();
-        }
-    }
+// Queue of the jobs a lean kernel leaves to the general one.  Word 0 is the lean kernel's slot counter, word 2 keeps the
+// count of the last launch (diagnostics); the list starts at word SLAM_DEFER_LIST and holds job index + 1, zero meaning
+// "no entry".  Every launch leaves the counter and the list at zero: the general kernel never reads the counter - its
+// workgroup b takes the slots b, b + grid, ... until it meets an empty one (the lean kernel fills slots from 0 upwards
+// without gaps) and empties every slot it takes, and its first workgroup resets the counter, which nobody else reads
+// before the next lean kernel starts.  So a launch depends on no host-side state, a captured launch replays as often as
+// wanted, and a launch with an empty queue costs each workgroup one load.
+__device__ __forceinline__ void queue_begin(int* queue) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { queue[2] = queue[0]; queue[0] = 0; }
 }
+// the job in slot q (wave-uniform), or -1 when the slot is empty; the slot is left empty
+__device__ __forceinline__ int queue_take(int* queue, int q) {
+    const int e = __builtin_amdgcn_readfirstlane(queue[SLAM_DEFER_LIST + q]);
+    if (e != 0 && threadIdx.x == 0) queue[SLAM_DEFER_LIST + q] = 0;
+    return e - 1;
+}
+__device__ __forceinline__ void queue_put(int* queue, int j) { queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j + 1; }
 
 // General single-search kernel.  queue == nullptr: workgroup b takes job b.  Otherwise the workgroups share out the jobs
 // the lean kernel queued (a later launch on the same stream: its counter and list are complete and visible).
@@ -258,13 +259,13 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void match_kernel(slam_pyr
         if (j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
         return;
     }
-    const int count = min(__builtin_amdgcn_readfirstlane(queue[0]), njobs);
-    for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        const int j = queue[SLAM_DEFER_LIST + q];
+    queue_begin(queue);
+    for (int q = blockIdx.x; q < njobs; q += gridDim.x) {
+        const int j = queue_take(queue, q);
+        if (j < 0) break;
         __syncthreads();                                   // the previous job's last readers of the dynamic LDS
-        if (j >= 0 && j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
+        if (j < njobs) match_job(pyr, jobs, j, blob, blob_bytes, scores, scores_len, out, force_direct, lds, plan);
     }
-    queue_done(queue, count);
 }
 
 // Lean single-search kernel: one matchFeatureInArea call whose candidate patches all lie inside the image, without a
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LEAN_SEARCH) void match_lea
     }
     if (threadIdx.x == 0) {
         if (o.ok) { slam_match_result r = {o.x, o.y, o.response, o.dx, o.dy, SLAM_HIP_OK}; out[j] = r; }
-        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
+        else queue_put(queue, j);
     }
 }
 
@@ -470,13 +471,13 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
         if (j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
         return;
     }
-    const int count = min(__builtin_amdgcn_readfirstlane(queue[0]), njobs);
-    for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        const int j = queue[SLAM_DEFER_LIST + q];
+    queue_begin(queue);                                    // see match_kernel
+    for (int q = blockIdx.x; q < njobs; q += gridDim.x) {
+        const int j = queue_take(queue, q);
+        if (j < 0) break;
         __syncthreads();                                   // the previous job's last readers of lc and the dynamic LDS
-        if (j >= 0 && j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
+        if (j < njobs) track_job(pyr, jobs, j, blob, blob_bytes, out, force_direct, lds, plan, lc);
     }
-    queue_done(queue, count);                              // see match_kernel
 }
 
 // Lean walk kernel: the level loop of SLAM::Feature::track (feature.cpp:117-172) for walks whose every level is an
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(sla
     const bool done = lean_walk(pyr, job, blob, blob_bytes, lds, lds_total, r);
     if (threadIdx.x == 0) {
         if (done) out[j] = r;
-        else queue[SLAM_DEFER_LIST + atomicAdd(queue, 1)] = j;
+        else queue_put(queue, j);
     }
 }
 
@@ -719,11 +720,11 @@ __global__ void score_formula_kernel(const unsigned long long* cc, const unsigne
     mto[i] = score_mt(cc[i], si[i], sp[i]);
 }
 
-// After the launch of the general kernel behind a lean one.  The general kernel is what returns the queue's counters to
-// zero; if it could not be launched the lean kernel's count would stay behind, so the counters are cleared here.
-int slam_queue_launched(slam_ctx* ctx, int* queue, hipError_t e) {
+// After the launch of the general kernel behind a lean one.  The general kernel is what returns the queue to zero; if
+// it could not be launched the lean kernel's entries would stay behind, so the queue is cleared here.
+int slam_queue_launched(slam_ctx* ctx, int* queue, int njobs, hipError_t e) {
     if (e == hipSuccess) return SLAM_HIP_OK;
-    (void)hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream);
+    (void)hipMemsetAsync(queue, 0, (SLAM_DEFER_LIST + (size_t)njobs) * sizeof(int), ctx->stream);
     return slam_set_error(ctx, SLAM_HIP_EHIP, "launch of the general kernel failed: %s", hipGetErrorString(e));
 }
 
@@ -797,7 +798,7 @@ extern "C" int slam_hip_match_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     hipLaunchKernelGGL(match_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes, ctx->stream,
                        pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_scores,
                        (unsigned long long)scores_len, d_out, 0, ctx->match_lds_bytes, queue);
-    return slam_queue_launched(ctx, queue, hipGetLastError());
+    return slam_queue_launched(ctx, queue, njobs, hipGetLastError());
 }
 
 static int mask_is_01(const uint8_t* m, size_t n) {
@@ -954,8 +955,8 @@ int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* 
     const int lds = ctx->lean_lds_once ? ctx->lean_lds_once : ctx->lean_lds_bytes;      // a host-table entry point may have sized this launch
     ctx->lean_lds_once = 0;
     // a queue shared by every context of the device (the no-alloc entry point) is cleared first: another context's
-    // failed launch must not leave its count behind
-    if (clear_first) SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, SLAM_DEFER_LIST * sizeof(int), ctx->stream));
+    // failed or overlapping launch must not leave its count or its entries behind
+    if (clear_first) SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, (SLAM_DEFER_LIST + (size_t)njobs) * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(track_lean_kernel, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), lds, ctx->stream, pyr->dev, d_jobs, njobs,
                        d_blob, (unsigned long long)blob_bytes, d_out, lds, queue);
     SLAM_HIP_CHECK(ctx, hipGetLastError());                // nothing was queued: the counters are still zero
@@ -964,7 +965,7 @@ int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* 
     hipLaunchKernelGGL(track_kernel, dim3(grid), dim3(SLAM_WG), ctx->match_lds_bytes,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
                        0, ctx->match_lds_bytes, queue);
-    return slam_queue_launched(ctx, queue, hipGetLastError());
+    return slam_queue_launched(ctx, queue, njobs, hipGetLastError());
 }
 
 extern "C" int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs,

@@ -31,7 +31,7 @@ struct slam_ctx {
     int lean_match_lds_bytes = 7680;   // LDS per job of the lean single-search kernel: 6 granules; its registers allow 20 jobs per CU (SLAM_HIP_SEARCH_LDS_KB / _BYTES)
     int lean_match_min_jobs = 64;      // smaller batches of single searches take the general kernel alone (SLAM_HIP_SEARCH_LEAN_MIN)
     // queue of walk jobs the lean kernel leaves to the general one: a counter word, then the job indices
-    int* d_queue = nullptr;            // 16 words (count, workgroups done, last launch's count), then the list of queued job indices
+    int* d_queue = nullptr;            // 16 words (slot counter, -, last launch's count), then the list of queued jobs (index + 1, 0 = empty)
     size_t queue_jobs = 0;
     int queue_last = 0;                // queue of the last launch: 0 = d_queue, -1 = the device's no-alloc scratch
     // one-level pyramid reused by slam_hip_match_feature_in_area while the image size stays the same

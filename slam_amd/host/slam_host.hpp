@@ -70,9 +70,9 @@ class SLAM {
 public:
     // SLAM.hpp:82-86
     struct Match {
-        cv::Point2f pos;
         int iFeature;
-        Match(const cv::Point2f& pos_, int iFeature_) : pos(pos_), iFeature(iFeature_) {}
+        cv::Point2f pos;
+        Match(const cv::Point2f& pos_, int iFeature_) : iFeature(iFeature_), pos(pos_) {}
     };
 
     // The members of SLAM::CameraState (SLAM.hpp:26-46) this path reads: P = K [R | -R t] (3x4),
@@ -119,12 +119,12 @@ public:
                                           bool useExactAreaMask = false);
 
     // matching.cpp:230-269 after the projections: every feature of one frame in one batched launch;
-    // keeps Match(pos, i) when response > threshold (matching.cpp:262-263).  stride 3 as matching.cpp:250.
+    // keeps Match(pos, i) when response > threshold (matching.cpp:254-255).  stride 3 as matching.cpp:243.
     static void matchPoints(const ImagePyramid<byte>& pyramid, const std::vector<Projection>& features,
                             std::vector<Match>& matches, float threshold = .95f, int stride = 3,
                             std::vector<float>* responses = nullptr);
 
-    // matching.cpp:250-264 with the reference's inputs: feature i is projected with p3ds[i]
+    // matching.cpp:250-261 with the reference's inputs: feature i is projected with p3ds[i]
     // (kalman.getPt3d(i), 3x1) and tracked, all features of the frame in one device pass.
     static void matchPoints(const ImagePyramid<byte>& pyramid, const CameraState& state,
                             const std::vector<Feature>& features, const std::vector<matf>& p3ds,

@@ -17,10 +17,11 @@ def shard_range(n_units, rank, world):
 
 def gather_records(local, device=None):
     """All-gather a rank-local 1-D numpy record array (any dtype); every rank gets the
-    concatenation in rank order.  Single-process: returns `local` unchanged."""
+    concatenation in rank order.  Without a process group: returns `local` unchanged (a group of one rank still
+    runs the collectives, on `device`)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size()
     dev = device if device is not None else torch.device("cpu")
@@ -42,7 +43,7 @@ def reduce_max_sum(elapsed, count, device=None):
     """(max over ranks of elapsed, sum over ranks of count) — what the benchmark reports."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(elapsed), float(count)
     dev = device if device is not None else torch.device("cpu")
     t = torch.tensor([float(elapsed)], dtype=torch.float64, device=dev)
@@ -50,3 +51,15 @@ def reduce_max_sum(elapsed, count, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), float(c.item())
+
+
+def reduce_max_vector(values, device=None):
+    """Element-wise max over ranks of a list of floats (the per-block times of the benchmark)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(v) for v in values]
+    dev = device if device is not None else torch.device("cpu")
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.cpu().tolist()]
