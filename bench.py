@@ -533,6 +533,89 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
     return out
 
 
+def prod_leg(api, capi, ctx, stream, dev, args, traffic):
+    """The reference's live point-tracking shape (not a BASELINE configuration): matchPoints' pyramid {1, 3} and stride 3
+    (matching.cpp:243-247) with the 81x81 descriptors new_image.cpp:80-82 creates, 64 features per 640x480 frame, masks
+    with cut corners (a warped quadrilateral), Feature::track's windows (feature.cpp:133-146): 14x14 on the stride-3
+    lattice at sub = 3 (27x27 template), 24x24 at full resolution; 256 frames."""
+    import torch
+    from slam_amd import synth
+    w, h, nfr, nfeat, ts, subs = W, H, 256, 64, 81, [1.0, 3.0]
+    rng = np.random.default_rng(0x51A40006)
+    shift = (4, -3)
+    big = synth.canvas_smooth(-8, -8, w + 16, h + 16, 0x51A40006)
+    f0, f1 = big[8:8 + h, 8:8 + w], big[8 + shift[1]:8 + shift[1] + h, 8 + shift[0]:8 + shift[0] + w]
+    f0, f1 = np.ascontiguousarray(f0), np.ascontiguousarray(f1)
+    pts = synth.feature_grid(w, h, nfeat, 70, rng)           # every window of the walk stays inside the image
+    lc = level_cells_and_bytes(ts, subs, STRIDE)             # levels 1, 0
+    parts, off, feats = [], 0, []
+    for (cx, cy) in pts:
+        proj = synth.cut_template(f0, cx, cy, ts, ts)
+        mask = np.ones_like(proj)
+        c = int(rng.integers(0, ts // 3 + 1))
+        for r in range(c):
+            mask[r, :c - r] = 0
+            mask[ts - 1 - r, ts - (c - r):] = 0
+        px, py = cx - shift[0] + float(rng.integers(-3, 4)) + 0.4, cy - shift[1] + float(rng.integers(-3, 4)) - 0.3
+        feats.append(dict(po=off, mo=off + proj.size, px=px, py=py, proj=proj, mask=mask))
+        parts += [proj.reshape(-1), mask.reshape(-1)]
+        off += 2 * proj.size
+    blob = np.concatenate(parts)
+    jobs = np.zeros(nfr * nfeat, TRACK_JOB_DT)
+    f_idx, k_idx = np.divmod(np.arange(nfr * nfeat), nfeat)
+    col = lambda key: np.array([ft[key] for ft in feats])[k_idx]
+    jobs["frame"], jobs["projw"], jobs["projh"] = f_idx, ts, ts
+    jobs["proj_off"], jobs["mask_off"], jobs["amask_off"] = col("po"), col("mo"), -1
+    jobs["px"], jobs["py"], jobs["threshold"], jobs["stride"] = col("px"), col("py"), THRESHOLD, STRIDE
+    d_fr = torch.from_numpy(f1).to(dev).unsqueeze(0).repeat(nfr, 1, 1).contiguous()
+    pyr = api.ImagePyramid(ctx, None, subs, device_ptr=d_fr.data_ptr(), pitch=w, frame_stride=w * h, shape=(nfr, h, w))
+    d_blob = torch.from_numpy(blob).to(dev)
+    d_jobs = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(dev)
+    d_res = torch.zeros(len(jobs) * TRACK_RES_DT.itemsize, dtype=torch.uint8, device=dev)
+    L = capi.lib()
+    P = lambda t: C.c_void_p(t.data_ptr())
+
+    def go():
+        capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), len(jobs), P(d_blob), blob.size, P(d_res)))
+    go()
+    torch.cuda.synchronize()
+    res = d_res.cpu().numpy().view(TRACK_RES_DT)
+    deferred = C.c_int32(0)
+    capi.check(ctx.handle, L.slam_hip_debug_walk_deferred(ctx.handle, C.byref(deferred)))
+    assert (res["status"] == 0).all()
+    parity = None
+    if not args.no_cpu:
+        from oracle import pyoracle as O
+        O.build()
+        levels = O.pyramid(f1, subs)
+        for k, ft in enumerate(feats):
+            r = O.track(levels, subs, ft["proj"], ft["mask"], ft["px"], ft["py"], THRESHOLD, STRIDE)
+            if not same_track(res[k], r):
+                raise SystemExit("PARITY FAILURE (prod) feature %d: gpu %s oracle %s" % (k, res[k], r))
+        same = res.reshape(nfr, nfeat)
+        for f in range(1, nfr):
+            assert np.array_equal(same[f], same[0])
+        parity = "all %d features of a frame equal the oracle bit for bit; the %d frames repeat them" % (nfeat, nfr)
+    lr = res["levels_run"]
+    cum_c = np.array([0] + list(np.cumsum([l["cells"] for l in lc])), np.float64)
+    cum_b = np.array([0] + list(np.cumsum([l["bytes"] for l in lc])), np.float64)
+    cum_m = np.array([0] + list(np.cumsum([l["macs"] for l in lc])), np.float64)
+    positions, alg, macs = float(cum_c[lr].sum()), float(cum_b[lr].sum()), float(cum_m[lr].sum())
+    tx = np.array([p[0] for p in pts])[k_idx] - shift[0]
+    ty = np.array([p[1] for p in pts])[k_idx] - shift[1]
+    tracked = float(np.mean((res["x"] == tx) & (res["y"] == ty) & (res["response"] > THRESHOLD)))
+    ms = timed(stream, go, max(5, args.steps))
+    ms_p = timed(stream, lambda: pyr.rebuild_d(d_fr.data_ptr(), w, w * h), max(5, args.steps))
+    out = search_report("track_lean_kernel@%d+track_kernel@4096" % len(jobs), "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
+                        {"workload": "the reference's live shape: %dx%d, %d features/frame, %dx%d masked descriptors, pyramid {1,3}, "
+                                     "stride 3, threshold %.2f; %d frames" % (w, h, nfeat, ts, ts, THRESHOLD, nfr),
+                         "jobs": len(jobs), "pyramid_ms": float(ms_p), "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
+                         "walked_all_levels": float((lr == 2).mean()), "tracked_fraction": tracked,
+                         "jobs_left_to_general_kernel": deferred.value, "parity": parity})
+    pyr.close()
+    return out
+
+
 def line_leg(api, capi, ctx, stream, dev, args, traffic):
     """The searches of LineFeature::track (lineFeature.cpp:120-165) as matchLines runs them (matching.cpp:273-277:
     pyramid {1,2}, stride 2): 3 lines per frame (new_image.cpp:80), 81x81 descriptors (new_image.cpp:82), the coarsest
@@ -848,6 +931,7 @@ def main(argv=None):
             side["fast"] = fast_leg(api, capi, ctx, stream, dev, args, traffic)
         side["c1"] = c1_leg(api, capi, ctx, stream, dev, args, traffic)
         side["c3"] = c3_leg(api, capi, ctx, stream, dev, args, traffic)
+        side["prod"] = prod_leg(api, capi, ctx, stream, dev, args, traffic)
         side["line_walk"] = line_leg(api, capi, ctx, stream, dev, args, traffic)
 
     if rank == 0:

@@ -142,9 +142,11 @@ __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah
     return ((nacc * 8 + 15) & ~15) + cap * 8 + ((lean_mcap(NG, th, true) * 4 + 15) & ~15) + (tile_bytes > raw_bytes ? tile_bytes : raw_bytes);
 }
 
-// accumulator index of the cell in tile column c (= o + x), row y, of a stride-1 search: strips of 4 columns run down
-// the rows (unit = strip * ah + row)
-__device__ __forceinline__ int lean_strip_cell(int c, int y, int ah) { return ((c >> 2) * ah + y) * 4 + (c & 3); }
+// Accumulators of a block of nu units with NC cells each: the {CC, SI} pair of cell k of unit u is pair k * nu + u, so
+// that the lanes of a flush - consecutive units - fall on consecutive pairs (unit-major pairs, 32 bytes apart, met in
+// 4 of the banks only: the flushes then made a third of all LDS cycles of a walk conflict cycles).  Pair of the cell in
+// tile column c (= o + x), row y, of a stride-1 search: strips of 4 columns run down the rows (unit = strip * rows + row).
+__device__ __forceinline__ int lean_strip_cell(int c, int y, int rows, int nu) { return (c & 3) * nu + (c >> 2) * rows + y; }
 
 // the score of a cell from its sums - the F32 formula (matching.cpp:70-72) or matchTemplate's (matching.cpp:152); the
 // caller has checked that the cell is visited
@@ -240,8 +242,8 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
         if (t0 + lane < ntask) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
-                __hip_atomic_fetch_add(acc + (unit * NC + k) * 2, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + (unit * NC + k) * 2 + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2 + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -492,7 +494,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 const int cy = (int)(((float)lane + 0.5f) * rnx), cx = lane - cy * nx;
                 const int x = cx * L.step, y = (r0 + cy) * L.step;
                 if (!(L.amask && L.amask[y * L.aw + x] == 0))
-                    best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b) : lane, nm, mt), (y << 16) | x);
+                    best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : lane, nm, mt), (y << 16) | x);
             }
         } else if (ncell <= NQ * SLAM_WG && nm.tn > 0.0) {
             // Single-precision estimates first (relative error below 1e-6): only cells within 1e-5 of the largest estimate
@@ -507,7 +509,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 auto cell_of = [&](int i, int& ai, int& key) {
                     const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                     const int x = cx * L.step, y = (r0 + cy) * L.step;
-                    ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                    ai = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                     key = (y << 16) | x;
                     return !(L.amask && L.amask[y * L.aw + x] == 0);
                 };
@@ -546,7 +548,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                         const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                         const int x = cx * L.step, y = (r0 + cy) * L.step;
                         if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0)) {
-                            ai[q] = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                            ai[q] = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                             key[q] = (y << 16) | x;
                             const unsigned CC = acc[2 * ai[q]], SI = acc[2 * ai[q] + 1];
                             if (SI != 0u) est[q] = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
@@ -574,7 +576,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                 const int x = cx * L.step, y = (r0 + cy) * L.step;
                 if (L.amask && L.amask[y * L.aw + x] == 0) continue;
-                const int ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                const int ai = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                 const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
                 float est = -FLT_MAX;
                 if (SI != 0u) est = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
@@ -588,14 +590,14 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 if (m1 != -FLT_MAX && m1 >= keep_from) {
                     const int cy = (int)(((float)i1 + 0.5f) * rnx), cx = i1 - cy * nx;
                     const int x = cx * L.step, y = (r0 + cy) * L.step;
-                    best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b) : i1, nm, mt), (y << 16) | x);
+                    best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i1, nm, mt), (y << 16) | x);
                 }
             } else {
                 for (int i = lane; i < ncell; i += SLAM_WG) {
                     const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                     const int x = cx * L.step, y = (r0 + cy) * L.step;
                     if (L.amask && L.amask[y * L.aw + x] == 0) continue;
-                    const int ai = strips ? lean_strip_cell(o + x, cy, rows_b) : i;
+                    const int ai = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                     const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
                     float est = -FLT_MAX;
                     if (SI != 0u) est = (float)CC * __builtin_amdgcn_rsqf((float)SI) * rn;
@@ -608,7 +610,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                 const int x = cx * L.step, y = (r0 + cy) * L.step;
                 if (L.amask && L.amask[y * L.aw + x] == 0) continue;
-                best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b) : i, nm, mt), (y << 16) | x);
+                best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i, nm, mt), (y << 16) | x);
             }
         }
     }
@@ -617,7 +619,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int qx = lx + (n == 0 ? -1 : n == 1 ? 1 : 0), qy = ly + (n == 2 ? -1 : n == 3 ? 1 : 0);
     const bool in = qx >= 0 && qy >= 0 && qx < L.aw && qy < L.ah;
     float v = -1.f;
-    if (in && !(L.amask && L.amask[qy * L.aw + qx] == 0)) v = lean_score(acc, lean_strip_cell(o + qx, qy - r0, rows_b), nm, mt);
+    if (in && !(L.amask && L.amask[qy * L.aw + qx] == 0)) v = lean_score(acc, lean_strip_cell(o + qx, qy - r0, rows_b, rows_b * upr), nm, mt);
     const float sl = __shfl(v, 0, 64), sr = __shfl(v, 1, 64), su = __shfl(v, 2, 64), sd = __shfl(v, 3, 64);
     const bool okl = __shfl((int)in, 0, 64) != 0, okr = __shfl((int)in, 1, 64) != 0;
     const bool oku = __shfl((int)in, 2, 64) != 0, okd = __shfl((int)in, 3, 64) != 0;
