@@ -31,9 +31,9 @@ def main():
             capi.check(ctx.handle, L.slam_hip_fast_detect_d(ctx.handle, C.c_void_p(d.data_ptr()), w, h, w, w * h, nfr, thr, 1,
                                                             C.c_void_p(d_out.data_ptr()), cap, C.c_void_p(d_cnt.data_ptr()),
                                                             C.c_void_p(d_scr.data_ptr()), sb))
-        for _ in range(3):
+        for _ in range(40):
             go()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
         for a, b in evs:
             a.record(stream); go(); b.record(stream)
         torch.cuda.synchronize()

@@ -310,7 +310,11 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
     // A template of at most 32 groups (the coarse levels of a walk) is not sorted into the two lists: compacting it
     // costs more instructions than masking every group of so short a list does.
-    const bool tiny = NG <= 32;
+    // (decided here, from sizes alone: the direct search of a few lattice cells further down needs no entry lists either)
+    const int dshift = nx * ny <= 4 ? 4 : nx * ny <= 8 ? 3 : nx * ny <= 16 ? 2 : 1;       // 2^dshift lanes per cell
+    const bool direct = !SEARCH && !strips && nx * ny <= 32 && ((L.th + (1 << dshift) - 1) >> dshift) * G <= 16 &&
+                        L.x0 + (nx - 1) * L.step + 4 * G <= L.w;
+    const bool tiny = direct || NG <= 32;
     unsigned sp_part = 0;
     int nA = 0, nB = 0;
     const float rG = __builtin_amdgcn_rcpf((float)G);
@@ -382,14 +386,60 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const Norms nm = make_norms(spfull);
     STAMP(51);
 
-    // ---- entry lists --------------------------------------------------------------------------------------------
-    const LeanSlices lsl = lean_pick_slices(bh * upr, nA, nB, strips);
+    // ---- a handful of lattice cells under a small template (the coarse levels of a walk) --------------------------------
+    // At most 32 cells and at most 16 template groups per lane: tile, lists and LDS accumulators would cost more than the sums themselves.
+    // Every cell gets P = 2^k lanes that split the template rows; a lane reads its windows straight from the image
+    // (unaligned dwords, served by the caches: the cells overlap) against the {P0, M} pairs staged above, the partial
+    // sums of a cell meet by DPP butterflies, and the cell's first lane scores it.  Same integer sums, same formula, same
+    // argmax rule as below.  (The last group's dword may reach up to 3 bytes past the template: it must stay inside
+    // the image row.  Off the lattice there is no sub-pixel fit - the neighbours are unvisited - so none is needed here.)
+    Best b = {-FLT_MAX, INT_MAX};
+    const LeanSlices lsl = direct ? LeanSlices{1, 0, 0} : lean_pick_slices(bh * upr, nA, nB, strips);
     const int S = lsl.S, na = lsl.na, nA1 = na * S;           // all-kept entries per slice; the rest of them joins the masked part
     const int nb = lsl.nb, nB1 = nb * S;
     // a mask with more partly kept groups than a warped quadrilateral has (never true for single searches)
-    if (!SEARCH && nB1 + 2 > lean_mcap(NG, L.th, true)) { LEAN_REJECT(4); return out; }
+    if (!SEARCH && !direct && nB1 + 2 > lean_mcap(NG, L.th, true)) { LEAN_REJECT(4); return out; }
     __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
-    if (tiny) {                                             // every group a masked entry, in template order
+    if (direct) {
+        const int ncell = nx * ny, pshift = dshift;
+        const int cell = lane >> pshift, part = lane & ((1 << pshift) - 1);
+        const bool live = cell < ncell;
+        const int cy = live ? (int)(((float)cell + 0.5f) * __builtin_amdgcn_rcpf((float)nx)) : 0, cx = live ? cell - cy * nx : 0;
+        const int x = cx * L.step, y = cy * L.step;
+        unsigned cc = 0, si = 0;
+        if (live) {
+            const uint8_t* cellp = L.im + (unsigned long long)(unsigned)(L.y0 + y) * L.ipitch + (unsigned)(L.x0 + x);
+            for (int u = part; u < L.th; u += 1 << pshift) {
+                const uint8_t* row = cellp + (unsigned)u * L.ipitch;
+                const lds_u64* pr = raw + u * G;
+                for (int gq = 0; gq < G; gq++) {
+                    unsigned w;
+                    __builtin_memcpy(&w, row + 4 * gq, 4);
+                    const unsigned long long pm = pr[gq];
+                    const unsigned wm = w & (unsigned)(pm >> 32);
+                    cc = __builtin_amdgcn_udot4(w, (unsigned)pm, cc, false);
+                    si = __builtin_amdgcn_udot4(wm, wm, si, false);
+                }
+            }
+        }
+        // the parts of a cell are 2, 4, 8 or 16 neighbouring lanes inside a row of 16: pairs, quads, half rows, rows
+        cc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)cc, 0xB1, 0xf, 0xf, false);
+        si += (unsigned)__builtin_amdgcn_update_dpp(0, (int)si, 0xB1, 0xf, 0xf, false);
+        if (pshift >= 2) {
+            cc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)cc, 0x4E, 0xf, 0xf, false);
+            si += (unsigned)__builtin_amdgcn_update_dpp(0, (int)si, 0x4E, 0xf, 0xf, false);
+        }
+        if (pshift >= 3) {
+            cc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)cc, 0x141, 0xf, 0xf, false);      // row_half_mirror
+            si += (unsigned)__builtin_amdgcn_update_dpp(0, (int)si, 0x141, 0xf, 0xf, false);
+        }
+        if (pshift >= 4) {
+            cc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)cc, 0x140, 0xf, 0xf, false);      // row_mirror
+            si += (unsigned)__builtin_amdgcn_update_dpp(0, (int)si, 0x140, 0xf, 0xf, false);
+        }
+        if (live && part == 0 && !(L.amask && L.amask[y * L.aw + x] == 0))
+            best_update(b, score_f32_n(cc, si, nm.p2f), (y << 16) | x);
+    } else if (tiny) {                                      // every group a masked entry, in template order
         if (lane < NG) {
             const unsigned long long r = raw[lane];
             const int u = (int)(((float)lane + 0.5f) * rG), gq = lane - u * G;
@@ -419,11 +469,10 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
 
     // ---- blocks of rows: tile, sums, scores; after the last one the argmax and, for the fit, the rows around it ----
     const float rnx = __builtin_amdgcn_rcpf((float)nx);
-    Best b = {-FLT_MAX, INT_MAX};
     int r0 = 0, rows_b = rows_all;                          // the block whose sums the accumulators hold
     int lx = 0, ly = 0;
     float bv = 0.f;
-    for (int blk = 0; blk <= nblk; blk++) {
+    for (int blk = direct ? nblk : 0; blk <= nblk; blk++) {
         if (blk == nblk) {
             // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The
             // wave's maximum first, then the smallest cell index among the lanes that hold it (cv::minMaxLoc: first
