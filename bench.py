@@ -46,7 +46,8 @@ HBM_COPY_GBS = 6290.0          # what a plain device-to-device copy reaches on t
 #    came near in that measurement.
 DOT4_PEAK_MEASURED = 256 * 4 * 64 * 4 / 4.25 * 2.4e9
 DOT4_PEAK_NOMINAL = 256 * 4 * 64 * 4 / 2.0 * 2.4e9
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+LDS_PEAK_BPS = 150e12           # ds_read_b64 / b128 with every CU streaming (256 B per clock per CU at 2.4 GHz: 157 TB/s nominal)
 
 TRACK_JOB_DT = np.dtype([("frame", "<i4"), ("projw", "<i4"), ("projh", "<i4"), ("flags", "<i4"),
                          ("proj_off", "<i8"), ("mask_off", "<i8"), ("px", "<f4"), ("py", "<f4"),
@@ -242,14 +243,37 @@ def same_track(g, r):
         np.float32(g["response"]).view(np.uint32) == np.float32(r["response"]).view(np.uint32)
 
 
+LDS_PROFILE = {}
+
+
 def load_traffic():
     """HBM bytes per launch of the kernels of this command, from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, read counter x2: profiles/tools/profile_bench.sh).  A profile of another workload
-    shape or an older kernel does not apply: the file names the shapes it was taken on."""
+    shape or an older kernel does not apply: the file names the shapes it was taken on.  The same file carries the
+    kernels' LDS-array counters (lds_report)."""
     if not os.path.exists(TRAFFIC_FILE):
         return {}
     with open(TRAFFIC_FILE) as fh:
-        return json.load(fh).get("kernels", {})
+        doc = json.load(fh)
+    LDS_PROFILE.clear()
+    LDS_PROFILE.update(doc.get("lds", {}))
+    return doc.get("kernels", {})
+
+
+def lds_report(ms, *keys):
+    """LDS figures of a leg from the committed counter pass (profiles/<round>_lds.txt): the share of all CU cycles in
+    which the LDS array was active, the share of those cycles that were bank-conflict cycles, and an upper bound on the
+    bytes per second through the array (conflict-free array cycles x 256 B, over this run's kernel time) against the
+    aggregate ds_read_b64 peak.  None when the profile does not hold the kernels."""
+    if not all(k in LDS_PROFILE for k in keys):
+        return None
+    a = sum(LDS_PROFILE[k]["array_cycles"] for k in keys)
+    c = sum(LDS_PROFILE[k]["conflict_cycles"] for k in keys)
+    cyc = sum(LDS_PROFILE[k]["cycles_per_xcd"] for k in keys)
+    bps = (a - c) * 256.0 / (ms * 1e-3)
+    return {"array_busy": a / (cyc * 256.0) if cyc else None, "conflict_share": c / a if a else None,
+            "bytes_per_s_upper_bound": bps, "peak_bytes_per_s": LDS_PEAK_BPS, "frac_of_peak": bps / LDS_PEAK_BPS,
+            "source": os.path.basename(TRAFFIC_FILE)}
 
 
 def traffic_of(traffic, *keys):
@@ -288,7 +312,8 @@ def search_report(name, kernel, ms, positions, alg_bytes, macs, traffic, extra=N
                         "frac": ach / HBM_PEAK_GBS, "traffic": tr, "algorithmic_bytes_per_launch": int(alg_bytes),
                         "u8_mac_per_s": macs / (ms * 1e-3),
                         "frac_of_packed_dot_peak": macs / (ms * 1e-3) / DOT4_PEAK_MEASURED,
-                        "frac_of_nominal_dot_peak": macs / (ms * 1e-3) / DOT4_PEAK_NOMINAL}}
+                        "frac_of_nominal_dot_peak": macs / (ms * 1e-3) / DOT4_PEAK_NOMINAL},
+           "lds": lds_report(ms, *name.split("+"))}
     if extra:
         out.update(extra)
     return out
@@ -606,12 +631,20 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
     tracked = float(np.mean((res["x"] == tx) & (res["y"] == ty) & (res["response"] > THRESHOLD)))
     ms = timed(stream, go, max(5, args.steps))
     ms_p = timed(stream, lambda: pyr.rebuild_d(d_fr.data_ptr(), w, w * h), max(5, args.steps))
-    out = search_report("track_lean_kernel@%d+track_kernel@4096" % len(jobs), "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
+
+    def one_frame():                                             # the reference's own call: the features of one frame
+        capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), nfeat, P(d_blob), blob.size, P(d_res)))
+    lat = timed(stream, one_frame, max(5, args.steps))
+    go()
+    # (no profile key: the general kernel runs with 4096 workgroups in every leg, and only here does it have work)
+    out = search_report("track_kernel@prod", "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
                         {"workload": "the reference's live shape: %dx%d, %d features/frame, %dx%d masked descriptors, pyramid {1,3}, "
                                      "stride 3, threshold %.2f; %d frames" % (w, h, nfeat, ts, ts, THRESHOLD, nfr),
                          "jobs": len(jobs), "pyramid_ms": float(ms_p), "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
                          "walked_all_levels": float((lr == 2).mean()), "tracked_fraction": tracked,
-                         "jobs_left_to_general_kernel": deferred.value, "parity": parity})
+                         "jobs_left_to_general_kernel": deferred.value, "parity": parity,
+                         "one_frame": {"features": nfeat, "ms": float(lat), "ms_min": lat.fastest,
+                                       "note": "launch to completion of one frame's walks (one wavefront each) between HIP events"}})
     pyr.close()
     return out
 
@@ -683,10 +716,30 @@ def line_leg(api, capi, ctx, stream, dev, args, traffic):
                   (aw + tc - 1) * (ah + tc - 1) + tc * tc + aw * ah + 20 + (5 + ds - 1) ** 2 + ds * ds + 20], np.float64)
     m = np.array([0, 2.0 * aw * ah * tc * tc, 2.0 * aw * ah * tc * tc + 2.0 * 25 * ds * ds])
     ms = timed(stream, go, max(5, args.steps))
+    # one frame's lines alone (the reference's own call pattern: three lines per frame): the coarsest search of each is
+    # cut into bands of rows over several wavefronts; beside it the same call with one wavefront per line
+    def one_frame(c):
+        def f():
+            capi.check(c.handle, L.slam_hip_line_track_batch_d(c.handle, pyr.handle, P(d_jobs), nline, P(d_blob), blob.size, P(d_res)))
+        return f
+    lat = timed(stream, one_frame(ctx), max(5, args.steps))
+    keep = os.environ.get("SLAM_HIP_LINE_BANDS")
+    os.environ["SLAM_HIP_LINE_BANDS"] = "1"
+    ctx1 = api.Context(ctx.device, stream=stream.cuda_stream)
+    if keep is None:
+        del os.environ["SLAM_HIP_LINE_BANDS"]
+    else:
+        os.environ["SLAM_HIP_LINE_BANDS"] = keep
+    lat1 = timed(stream, one_frame(ctx1), max(5, args.steps))
+    ctx1.close()
+    go()                                                          # d_res holds the whole batch again
     out = search_report("line_track_kernel@%d" % len(jobs), "line_track_kernel", ms, float(c[lr].sum()), float(b[lr].sum()), float(m[lr].sum()), traffic,
                         {"workload": "line walk: %dx%d, %d lines/frame, %dx%d descriptors, pyramid {1,2}, stride 2, %dx%d disc-union "
                                      "area on the coarsest level; %d frames" % (w, h, nline, ds, ds, aw, ah, nfr),
-                         "jobs": len(jobs), "refined_at_full_resolution": float((lr == 2).mean()), "parity": parity})
+                         "jobs": len(jobs), "refined_at_full_resolution": float((lr == 2).mean()), "parity": parity,
+                         "one_frame": {"lines": nline, "ms": float(lat), "ms_min": lat.fastest,
+                                       "ms_one_wavefront_per_line": float(lat1), "bands_per_line": min(8, max(1, 3072 // nline)),
+                                       "note": "launch to completion of one frame's lines between HIP events"}})
     pyr.close()
     return out
 
@@ -972,6 +1025,7 @@ def main(argv=None):
                          # the HBM fraction this workload would reach if nothing but its multiply-accumulates were issued
                          "hbm_frac_at_measured_dot_peak": alg_bytes / (macs / DOT4_PEAK_MEASURED) / 1e9 / HBM_PEAK_GBS,
                          "hbm_frac_at_nominal_dot_peak": alg_bytes / (macs / DOT4_PEAK_NOMINAL) / 1e9 / HBM_PEAK_GBS},
+            "lds": lds_report(kern_ms, "track_lean_kernel@%d" % (8 * ((njobs + 7) // 8)), "track_kernel@%d" % min(njobs, 4096)),
             "cpu_baseline": cpu,
             "with_h2d": with_h2d,
             # the other kernels and configurations BASELINE.json names, measured in the same run (outside the timed steps)

@@ -73,7 +73,28 @@ def main():
     corr = factor.get("calib_read_b32", 2.0)
     lines += ["", "correction used for dword-per-lane reads: x%.3f" % corr, ""]
     lines.append("%-58s %8s %14s %14s %16s" % ("kernel@workgroups", "launches", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "HBM_bytes/launch"))
-    out = {"sequences_per_gpu": nseq, "avg_kernel_us": avg, "kernels": {}}
+    out = {"sequences_per_gpu": nseq, "avg_kernel_us": avg, "kernels": {}, "lds": {}}
+    # LDS pass: LDS-array cycles (all CUs summed), the conflict cycles among them, and GRBM_GUI_ACTIVE (graphics-clock
+    # cycles while the kernel ran, summed over the 8 XCDs) per launch.  busy = array cycles / (cycles per XCD x 256 CUs);
+    # bytes <= conflict-free array cycles x 256 B (the array's width): an upper bound on what the kernel moved through it.
+    lds_db = os.path.join(src, "lds", "lds_results.db")
+    if os.path.exists(lds_db):
+        idx = counter_by_kernel(lds_db, "SQ_LDS_IDX_ACTIVE")
+        bc = counter_by_kernel(lds_db, "SQ_LDS_BANK_CONFLICT")
+        ins = counter_by_kernel(lds_db, "SQ_INSTS_LDS")
+        grbm = counter_by_kernel(lds_db, "GRBM_GUI_ACTIVE")
+        ll = ["rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 --warmup 1 --repeats 2 --no-cpu --no-fast-sparse",
+              "per launch, means over launches; array cycles are summed over the 256 CUs, GRBM cycles over the 8 XCDs", "",
+              "%-44s %8s %14s %14s %12s %12s %8s %10s" % ("kernel@workgroups", "launches", "array_cycles", "conflict_cyc", "lds_insts", "cyc_per_xcd", "busy", "conflicts")]
+        for k in sorted(idx):
+            a, c, n, g = idx[k][1], bc.get(k, (0, 0.0))[1], ins.get(k, (0, 0.0))[1], grbm.get(k, (0, 0.0))[1] / 8.0
+            busy = a / (g * 256.0) if g else 0.0
+            out["lds"][k] = {"array_cycles": a, "conflict_cycles": c, "lds_insts": n, "cycles_per_xcd": g, "array_busy": busy,
+                             "bytes_upper_bound": (a - c) * 256.0}
+            ll.append("%-44s %8d %14.0f %14.0f %12.0f %12.0f %7.1f%% %9.1f%%" % (k[:44], idx[k][0], a, c, n, g, 100 * busy, 100 * c / a if a else 0))
+        with open(os.path.join(prof, tag + "_lds.txt"), "w") as fh:
+            fh.write("\n".join(ll) + "\n")
+        print("\n".join(ll))
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, (0, 0.0))
         w = write.get(k, (0, 0.0))

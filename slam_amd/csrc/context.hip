@@ -59,6 +59,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     if (sm && atoi(sm) >= 1) c->lean_match_min_jobs = atoi(sm);
     const char* lk = getenv("SLAM_HIP_MATCH_LDS_KB");
     if (lk && atoi(lk) >= 4 && atoi(lk) <= 63) c->match_lds_bytes = c->line_lds_bytes = atoi(lk) * 1024;
+    const char* lbn = getenv("SLAM_HIP_LINE_BANDS");
+    if (lbn && atoi(lbn) >= 1 && atoi(lbn) <= 8) c->line_bands = atoi(lbn);
     const int rc = slam_track_scratch_init(c);             // this device's copy of the no-alloc walk queue
     if (rc != SLAM_HIP_OK) {
         strncpy(g_create_err, c->err, sizeof(g_create_err) - 1);
@@ -78,6 +80,7 @@ extern "C" int slam_hip_destroy(slam_ctx* ctx) {
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
     if (ctx->mfa_pyr) { slam_hip_pyramid_destroy(ctx, ctx->mfa_pyr); ctx->mfa_pyr = nullptr; }
     if (ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx->d_bands) (void)hipFree(ctx->d_bands);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -615,6 +615,71 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(sla
     }
 }
 
+// A small batch of line walks (the reference tracks three lines per frame, new_image.cpp:80) leaves most of the chip
+// idle while one wavefront per line searches the coarsest level - 2400 cells under a 40x40 template for an 81x81
+// descriptor.  For such batches the coarsest search (lineFeature.cpp:124-127) is cut into `nb` bands of rows, one
+// wavefront each (line_coarse_kernel), and line_track_kernel takes the first of the bands' maxima in band order - the
+// first maximum in row-major order, what cv::minMaxLoc returns (matching.cpp:221-227).  Only areas whose candidate
+// patches all lie inside the image are cut (every cell of such an area is scored by matchTemplate's rule whatever the
+// stride or the area mask, matching.cpp:151-153, so a band is searched exactly as part of the whole); any other area
+// is marked invalid here and searched whole by line_track_kernel.
+struct LineBand { int x, y; float response; int valid; };
+
+// job checks shared by the two line kernels
+__device__ __forceinline__ bool line_job_ok(const slam_pyr_dev& pyr, const slam_line_job& job, unsigned long long blob_bytes) {
+    return job.frame >= 0 && job.frame < pyr.nframes && job.dw >= 1 && job.dh >= 1 && job.dw <= SLAM_MAX_TMPL &&
+           job.dh <= SLAM_MAX_TMPL && job.stride >= 1 && job.stride <= 1024 && job.aw >= 1 && job.ah >= 1 &&
+           job.aw <= (1 << 12) && job.ah <= (1 << 12) &&
+           job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28) &&
+           span_ok(job.desc_off, (long long)job.dw * job.dh, blob_bytes) &&
+           span_ok(job.amask_off, (long long)job.aw * job.ah, blob_bytes) && job.threshold == job.threshold;
+}
+
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE) void line_coarse_kernel(slam_pyr_dev pyr, const slam_line_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob, unsigned long long blob_bytes,
+                                                        LineBand* __restrict__ bands, int nb, int force_direct, int lds_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const LdsPlan plan = make_lds_plan(lds_total);
+    const int j = blockIdx.x, band = blockIdx.y;
+    if (j >= njobs || band >= nb) return;
+    const slam_line_job job = jobs[j];
+    LineBand out = {0, 0, -1.f, 0};
+    if (line_job_ok(pyr, job, blob_bytes)) {
+        const int i = pyr.nlev - 1;
+        float sub = 1.f; int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
+#pragma unroll
+        for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++)
+            if (l == i) { sub = pyr.lev[l].sub; lw = pyr.lev[l].w; lh = pyr.lev[l].h; lp = pyr.lev[l].pitch; ls = pyr.lev[l].frame_stride; ld = pyr.lev[l].data; }
+        Tmpl t;
+        t.patch = blob + job.desc_off; t.mask = nullptr;
+        t.srcw = job.dw; t.srch = job.dh;
+        t.limit = blob + blob_bytes;
+        const float areaRes = __fdiv_rn(1.f, sub);                                  // lineFeature.cpp:30
+        t.tw = __builtin_amdgcn_readfirstlane(round_f2i(__fmul_rn((float)job.dw, areaRes)));   // lineFeature.cpp:124
+        t.th = __builtin_amdgcn_readfirstlane(round_f2i(__fmul_rn((float)job.dh, areaRes)));
+        if (t.tw > 0 && t.th > 0 && t.tw <= 2 * SLAM_MAX_TMPL && t.th <= 2 * SLAM_MAX_TMPL) {
+            t.resized = !(t.tw == job.dw && t.th == job.dh);
+            t.scale_x = 1.0; t.scale_y = 1.0;
+            if (t.resized) { t.scale_x = resize_scale(job.dw, t.tw); t.scale_y = resize_scale(job.dh, t.th); }
+            const uint8_t* im = ld + (long long)job.frame * ls;
+            const uint8_t* am = blob + job.amask_off;
+            const Geo g = make_geo(im, lw, lh, lp, t.tw, t.th, job.ax, job.ay, job.aw, job.ah, am, job.stride, false, false);
+            const bool interior = !g.reject && g.xl0 == 0 && g.yl0 == 0 && g.xl1 == g.aw && g.yl1 == g.ah &&
+                                  g.aw == job.aw && g.ah == job.ah && g.ah >= nb;
+            if (interior) {
+                const int y0 = small_div_u(band * g.ah, nb), y1 = small_div_u((band + 1) * g.ah, nb);
+                const Geo gb = make_geo(im, lw, lh, lp, t.tw, t.th, job.ax, job.ay + y0, job.aw, y1 - y0,
+                                        am + (long long)y0 * job.aw, job.stride, false, false);
+                STAMP_DECL;
+                const CoreOut o = match_core(gb, t, nullptr, lds, plan, force_direct != 0, false, 0.0 STAMP_PASS);
+                out.x = o.x; out.y = o.y; out.response = o.response; out.valid = 1;
+            }
+        }
+    }
+    if (threadIdx.x == 0) bands[(size_t)j * nb + band] = out;
+}
+
 // The searches of SLAM::LineFeature::track (lineFeature.cpp:120-165) for one line feature: the
 // descriptor resized to the coarsest level and searched without a patch mask inside the area mask
 // (lineFeature.cpp:124-127), then, while the response stays above 0.67*threshold, each finer level in
@@ -622,7 +687,8 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(sla
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE) void line_track_kernel(slam_pyr_dev pyr, const slam_line_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
-                                                        slam_track_result* __restrict__ out, int force_direct, int lds_total) {
+                                                        slam_track_result* __restrict__ out, int force_direct, int lds_total,
+                                                        const LineBand* __restrict__ bands, int nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     lds_u8* lds = (lds_u8*)dyn_lds;
     const LdsPlan plan = make_lds_plan(lds_total);
@@ -630,12 +696,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE) void line_track_kerne
     if (j >= njobs) return;
     const slam_line_job job = jobs[j];
     const int tid = threadIdx.x;
-    const bool ok = job.frame >= 0 && job.frame < pyr.nframes && job.dw >= 1 && job.dh >= 1 && job.dw <= SLAM_MAX_TMPL &&
-                    job.dh <= SLAM_MAX_TMPL && job.stride >= 1 && job.stride <= 1024 && job.aw >= 1 && job.ah >= 1 &&
-                    job.aw <= (1 << 12) && job.ah <= (1 << 12) &&
-                    job.ax > -(1 << 28) && job.ax < (1 << 28) && job.ay > -(1 << 28) && job.ay < (1 << 28) &&
-                    span_ok(job.desc_off, (long long)job.dw * job.dh, blob_bytes) &&
-                    span_ok(job.amask_off, (long long)job.aw * job.ah, blob_bytes) && job.threshold == job.threshold;
+    const bool ok = line_job_ok(pyr, job, blob_bytes);
     if (!ok) {
         if (tid == 0) { slam_track_result r = {-1, -1, -1.f, 0.f, 0.f, 0, SLAM_HIP_EINVAL}; out[j] = r; }
         return;
@@ -685,7 +746,34 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE) void line_track_kerne
         int mx = 0, my = 0;
         sdx = 0.f; sdy = 0.f;
         levels_run++;
-        if (g.reject) response = -1.f;                        // matching.cpp:26-30
+        // the coarsest level of a small batch: searched in bands by line_coarse_kernel (all bands valid, or none)
+        bool banded = false;
+        if (coarsest && bands && nb > 1 && !g.reject) {
+            const LineBand* bj = bands + (size_t)j * nb;
+            banded = true;
+            LineBand best = {0, 0, -FLT_MAX, 0};
+            for (int k = 0; k < nb; k++) {                    // wave-uniform loads
+                const LineBand bk = bj[k];
+                banded = banded && bk.valid != 0;
+                if (bk.response > best.response) best = bk;   // strict: the first band holding the maximum keeps it
+            }
+            if (banded) {
+                mx = __builtin_amdgcn_readfirstlane(best.x); my = __builtin_amdgcn_readfirstlane(best.y);
+                response = uni_f32(best.response);
+                // If the walk ends here it reports this level's sub-pixel fit: the peak's neighbours may lie in another
+                // band, so the (at most) three rows around it are searched once more as an area of their own - the
+                // peak is their first maximum too, and their cells are the area's cells.
+                if (pyr.nlev == 1 || !((double)response > keep_above)) {
+                    const int ly = my - g.ay, r0 = max(ly - 1, 0), r1 = min(ly + 1, g.ah - 1);
+                    const Geo g3 = make_geo(ld + (long long)job.frame * ls, lw, lh, lp, t.tw, t.th, ax, ay + r0, aw, r1 - r0 + 1,
+                                            am + (long long)r0 * aw, stride, false, false);
+                    const CoreOut o = match_core(g3, t, nullptr, lds, plan, force_direct != 0, true, 0.0 STAMP_PASS);
+                    sdx = o.dx; sdy = o.dy;
+                }
+            }
+        }
+        if (banded) {}
+        else if (g.reject) response = -1.f;                   // matching.cpp:26-30
         else {
             const CoreOut o = match_core(g, t, nullptr, lds, plan, force_direct != 0, true, 0.0 STAMP_PASS);
             mx = o.x; my = o.y; response = o.response; sdx = o.dx; sdy = o.dy;
@@ -1036,9 +1124,33 @@ extern "C" int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, c
     if (rc != SLAM_HIP_OK) return rc;
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // A batch too small to fill the chip with one wavefront per line (the kernel's registers allow three per SIMD:
+    // 3072 at once) has its coarsest searches cut into bands of rows, up to 8 per line (line_coarse_kernel).
+    int nb = ctx->line_bands > 0 ? ctx->line_bands : 3072 / njobs;
+    nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+    LineBand* d_bands = nullptr;
+    if (nb > 1) {
+        const size_t need = (size_t)njobs * nb * sizeof(LineBand);
+        if (need > ctx->bands_bytes) {                         // grown on demand, like the walk queue
+            SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_bands) { SLAM_HIP_CHECK(ctx, hipFree(ctx->d_bands)); ctx->d_bands = nullptr; ctx->bands_bytes = 0; }
+            const size_t want = need * 2 + 4096;
+            if (hipMalloc(&ctx->d_bands, want) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->d_bands = nullptr;
+                nb = 1;                                        // no room for the bands: one wavefront per line
+            } else ctx->bands_bytes = want;
+        }
+        d_bands = (LineBand*)ctx->d_bands;
+    }
+    if (nb > 1) {
+        hipLaunchKernelGGL(line_coarse_kernel, dim3(njobs, nb), dim3(SLAM_WG), ctx->line_lds_bytes, ctx->stream, pyr->dev, d_jobs,
+                           njobs, d_blob, (unsigned long long)blob_bytes, d_bands, nb, ctx->force_direct, ctx->line_lds_bytes);
+        SLAM_HIP_CHECK(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(line_track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->line_lds_bytes,
                        ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
-                       ctx->force_direct, ctx->line_lds_bytes);
+                       ctx->force_direct, ctx->line_lds_bytes, (const LineBand*)d_bands, nb);
     SLAM_HIP_CHECK(ctx, hipGetLastError());
     return SLAM_HIP_OK;
 }

@@ -34,6 +34,10 @@ struct slam_ctx {
     int* d_queue = nullptr;            // 16 words (slot counter, -, last launch's count), then the list of queued jobs (index + 1, 0 = empty)
     size_t queue_jobs = 0;
     int queue_last = 0;                // queue of the last launch: 0 = d_queue, -1 = the device's no-alloc scratch
+    // band results of the coarsest level of small line-walk batches (line_coarse_kernel), grown on demand
+    void* d_bands = nullptr;
+    size_t bands_bytes = 0;
+    int line_bands = 0;                // SLAM_HIP_LINE_BANDS: bands per line (1 = never cut), 0 = by batch size
     // one-level pyramid reused by slam_hip_match_feature_in_area while the image size stays the same
     slam_pyr* mfa_pyr = nullptr;
     int mfa_w = 0, mfa_h = 0;

@@ -116,6 +116,40 @@ def test_line_track_matches_oracle(ctx, oracle, subs, half, n):
     assert got[-2]["response"] == -1.0 and (got[-2]["x"], got[-2]["y"]) == (0, 0)
 
 
+@pytest.mark.parametrize("bands", [1, 2, 3, 5, 8])
+def test_line_walks_do_not_depend_on_the_band_count(oracle, bands, monkeypatch):
+    """Small batches have their coarsest search cut into bands of rows, one wavefront each (by batch size; forced here
+    through SLAM_HIP_LINE_BANDS): the results - the sub-pixel fit of walks that end on the coarsest level included,
+    whose neighbours may sit in another band - equal the oracle's for every band count; areas over the image border
+    or lower than the band count are searched whole."""
+    monkeypatch.setenv("SLAM_HIP_LINE_BANDS", str(bands))
+    rng = np.random.default_rng(160 + SOAK_SEED)
+    w, h = 640, 480
+    shift = (4, -3)
+    f0, f1 = synth.frame(w, h, 29 + SOAK_SEED), synth.frame(w, h, 29 + SOAK_SEED, shift)
+    with api.Context(0) as c:
+        for subs, half, n in (([1.0, 2.0], 20, 12), ([2.0], 16, 6), ([1.0, 2.0, 4.0], 12, 8)):
+            jobs = _line_jobs(rng, w, h, subs, n, half, f0, shift)
+            for j in jobs:
+                j["area_mask"] = oracle.disc_mask(j["area"][2], j["area"][3], j["circles"])
+            jobs.append(dict(jobs[0], area=(-5, -7, 30, 25), area_mask=oracle.disc_mask(30, 25, [[12, 12, 11]])))      # over the corner
+            jobs.append(dict(jobs[1], threshold=1.5))                                       # ends on the coarsest level
+            jobs.append(dict(jobs[2], area=(jobs[2]["area"][0], jobs[2]["area"][1], 9, 2), area_mask=np.full((2, 9), 255, np.uint8)))  # two rows
+            jobs.append(dict(jobs[3], descriptor=np.zeros_like(jobs[3]["descriptor"])))       # every score equal: the first cell wins
+            pyr = api.ImagePyramid(c, f1, subs)
+            try:
+                got = api.line_track_batch(c, pyr, jobs)
+            finally:
+                pyr.close()
+            levels = oracle.pyramid(f1, subs)
+            for j, g in zip(jobs, got):
+                r = oracle.line_track(levels, subs, j["descriptor"], j["area"], j["area_mask"], j["threshold"], j["stride"])
+                assert g["status"] == 0
+                assert (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"]), (bands, j["area"], g, r)
+                for k in ("response", "dx", "dy"):
+                    assert np.float32(g[k]).view(np.uint32) == np.float32(r[k]).view(np.uint32), (bands, k, j["area"], g, r)
+
+
 def test_golden_projection_line_newpoint_vectors_on_gpu(ctx):
     """The committed vectors for Feature::project + track, the line masks and walks and the new-point selection
     (tests/golden/make_golden.py), reproduced by the HIP path without the oracle in the loop."""
