@@ -82,6 +82,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle: no parity gates, no cpu_baseline")
     ap.add_argument("--no-side", action="store_true", help="skip the extra legs (C1, C3, line walk, FAST)")
     ap.add_argument("--no-fast", action="store_true", help="skip the FAST (C4) leg")
+    ap.add_argument("--legs", default="fast,c1,c3,prod,line",
+                    help="the extra legs to run, of fast,c1,c3,prod,line (profiling: the general walk kernel has work in the prod leg only)")
     ap.add_argument("--no-fast-sparse", action="store_true",
                     help="FAST leg at threshold 10 only (profiling: keeps one kind of launch per kernel name)")
     ap.add_argument("--repeats", type=int, default=0,
@@ -636,7 +638,7 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
         capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), nfeat, P(d_blob), blob.size, P(d_res)))
     lat = timed(stream, one_frame, max(5, args.steps))
     go()
-    # (no profile key: the general kernel runs with 4096 workgroups in every leg, and only here does it have work)
+    # (a profile key of its own: the general kernel runs with 4096 workgroups in every leg, and only here does it have work)
     out = search_report("track_kernel@prod", "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
                         {"workload": "the reference's live shape: %dx%d, %d features/frame, %dx%d masked descriptors, pyramid {1,3}, "
                                      "stride 3, threshold %.2f; %d frames" % (w, h, nfeat, ts, ts, THRESHOLD, nfr),
@@ -980,12 +982,17 @@ def main(argv=None):
     side = {}
     if rank == 0 and world == 1 and not args.no_side:
         traffic = load_traffic()
-        if not args.no_fast:
+        legs = set(args.legs.split(","))
+        if not args.no_fast and "fast" in legs:
             side["fast"] = fast_leg(api, capi, ctx, stream, dev, args, traffic)
-        side["c1"] = c1_leg(api, capi, ctx, stream, dev, args, traffic)
-        side["c3"] = c3_leg(api, capi, ctx, stream, dev, args, traffic)
-        side["prod"] = prod_leg(api, capi, ctx, stream, dev, args, traffic)
-        side["line_walk"] = line_leg(api, capi, ctx, stream, dev, args, traffic)
+        if "c1" in legs:
+            side["c1"] = c1_leg(api, capi, ctx, stream, dev, args, traffic)
+        if "c3" in legs:
+            side["c3"] = c3_leg(api, capi, ctx, stream, dev, args, traffic)
+        if "prod" in legs:
+            side["prod"] = prod_leg(api, capi, ctx, stream, dev, args, traffic)
+        if "line" in legs:
+            side["line_walk"] = line_leg(api, capi, ctx, stream, dev, args, traffic)
 
     if rank == 0:
         traffic = load_traffic()

@@ -47,7 +47,8 @@ typedef struct slam_pyr slam_pyr;
  * ------------------------------------------------------------------------------------------- */
 int slam_hip_create(int device, slam_ctx** out);
 int slam_hip_destroy(slam_ctx* ctx);
-/* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the context's own. */
+/* Use an existing hipStream_t (e.g. the caller's framework stream); NULL restores the context's own.  Waits for the
+ * work queued on the stream used so far: the context's own buffers are ordered by one stream. */
 int slam_hip_set_stream(slam_ctx* ctx, void* hip_stream);
 int slam_hip_synchronize(slam_ctx* ctx);
 /* LDS bytes each search job (one wavefront) may use: a multiple of 64 in [4096, 64512], default
@@ -356,6 +357,10 @@ typedef struct slam_line_job {
  * offset of the last level searched.  A level whose resized descriptor would be empty gives (-1,-1),
  * response -1 (cv::resize would throw there).  The area-size cap of lineFeature.cpp:81-84 is the
  * caller's (it precedes the mask). */
+/* A batch of fewer than 1536 lines (the reference tracks three per frame, new_image.cpp:80) has each line's coarsest
+ * search cut into up to 8 bands of rows, one wavefront each (one launch more; same results); the band results live in
+ * a buffer of the context that grows when a batch needs more than any before it - the only allocation this entry point
+ * can make. */
 int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* d_jobs,
                                 int njobs, const uint8_t* d_blob, size_t blob_bytes,
                                 slam_track_result* d_out);

@@ -103,8 +103,11 @@ cv::Point2i SLAM::matchFeatureInArea(const cv::Mat_<byte>& im, const cv::Mat_<by
     // A whole level of a live pyramid (same buffer, same shape)?  Then search the resident level: the call uploads
     // the patch and the masks only.  The levels are snapshots taken when the pyramid was built; nothing in the
     // reference writes to them afterwards (imagePyramid.hpp:15-30), and writes to `images` would not be seen here.
+    // A caller that edits `pyramid.images[i]` in place (the member is public and writable, imagePyramid.hpp:12) sets
+    // SLAM_HIP_NO_RESIDENT_LEVELS=1: every call then uploads the image it is given, as the reference would read it.
+    static const bool no_resident = [] { const char* e = std::getenv("SLAM_HIP_NO_RESIDENT_LEVELS"); return e && e[0] == '1'; }();
     const std::vector<const ImagePyramid<byte>*>& live = slamhip::live_pyramids();
-    for (size_t k = 0; k < live.size(); k++) {
+    for (size_t k = 0; k < live.size() && !no_resident; k++) {
         const int level = live[k]->levelOf(im);
         if (level < 0) continue;
         if (patch.cols < 1 || patch.rows < 1 || stride < 1) break;          // let the generic entry point report it
