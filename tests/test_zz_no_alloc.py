@@ -60,6 +60,33 @@ def test_noalloc_walk_equals_the_allocating_entry_point_twice_in_a_row():
             pyr.close()
 
 
+def test_noalloc_walk_leaves_the_free_device_memory_unchanged():
+    """hipMemGetInfo before and after a run of calls (through torch, which holds no cached block of its own here): the
+    entry point allocates nothing, whatever the batch size - also a first batch larger than any the context has seen,
+    which makes the allocating entry point grow its queue."""
+    import torch
+    import bench
+    from slam_amd import api, capi
+    L = capi.lib()
+    with api.Context(0) as ctx:
+        frames, jobs, blob = _workload(40, 905)
+        pyr = api.ImagePyramid(ctx, frames, bench.SUBS)
+        d_jobs = api.DeviceBuffer(ctx, host=jobs.view(np.uint8).reshape(-1))
+        d_blob = api.DeviceBuffer(ctx, host=blob)
+        d_out = api.DeviceBuffer(ctx, nbytes=len(jobs) * bench.TRACK_RES_DT.itemsize, fill=0)
+        try:
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            free0, _ = torch.cuda.mem_get_info(0)
+            for n in (64, len(jobs), 7):
+                capi.check(ctx.handle, L.slam_hip_track_batch_noalloc_d(ctx.handle, pyr.handle, d_jobs.ptr, n, d_blob.ptr, blob.size, d_out.ptr))
+            ctx.synchronize()
+            free1, _ = torch.cuda.mem_get_info(0)
+            assert free1 == free0, (free0, free1)
+        finally:
+            d_jobs.free(); d_blob.free(); d_out.free(); pyr.close()
+
+
 def test_noalloc_walk_rejects_batches_beyond_its_queue():
     import bench
     from slam_amd import api, capi
