@@ -84,6 +84,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-fast", action="store_true", help="skip the FAST (C4) leg")
     ap.add_argument("--legs", default="fast,c1,c3,prod,line",
                     help="the extra legs to run, of fast,c1,c3,prod,line (profiling: the general walk kernel has work in the prod leg only)")
+    ap.add_argument("--c3-walk-lds", type=int, default=10240, help="LDS bytes per walk of the lean kernel in the C3 leg")
+    ap.add_argument("--c3-chunks", action="store_true", help="C3 leg through the lean kernel's build with template chunks")
+    ap.add_argument("--prod-walk-lds", type=int, default=15360,
+                    help="LDS bytes per walk of the lean kernel's chunked build in the prod leg (0: general kernel only)")
     ap.add_argument("--no-fast-sparse", action="store_true",
                     help="FAST leg at threshold 10 only (profiling: keeps one kind of launch per kernel name)")
     ap.add_argument("--repeats", type=int, default=0,
@@ -515,7 +519,8 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
     def go():
         capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), len(jobs), P(d_blob), blob.size, P(d_res)))
     # 31x31 templates: the lean walk kernel needs 11 KB of LDS per walk for the full-resolution level (include/slam_hip.h)
-    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 10240))     # 8 LDS granules of 1280 bytes: 16 walks per CU
+    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, args.c3_walk_lds))     # 10240: 8 LDS granules of 1280 bytes, 16 walks per CU
+    capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, int(args.c3_chunks)))
     go()
     torch.cuda.synchronize()
     res = d_res.cpu().numpy().view(TRACK_RES_DT)
@@ -554,8 +559,9 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
                                      "(area masks) on the coarsest level, stride 3; %d frames" % (w, h, nfeat, ts, ts, nfr),
                          "jobs": len(jobs), "pyramid_ms": ms_p, "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
                          "walked_all_levels": float((lr == 4).mean()), "jobs_left_to_general_kernel": deferred.value,
-                         "walk_lds_bytes": 10240, "parity": parity})
-    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 7680))      # back to the default
+                         "walk_lds_bytes": args.c3_walk_lds, "walk_chunks": bool(args.c3_chunks), "parity": parity})
+    capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 0))
+    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 7680))      # back to the defaults
     pyr.close()
     return out
 
@@ -602,6 +608,12 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
     L = capi.lib()
     P = lambda t: C.c_void_p(t.data_ptr())
 
+    # 81x81 descriptors do not fit the lean walk kernel's LDS whole: its build that takes the template in chunks of rows,
+    # with 12 granules of 1280 bytes per walk (10 walks per CU); 0 leaves every walk to the general kernel
+    if args.prod_walk_lds:
+        capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, args.prod_walk_lds))
+        capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 1))
+
     def go():
         capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), len(jobs), P(d_blob), blob.size, P(d_res)))
     go()
@@ -645,8 +657,11 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
                          "jobs": len(jobs), "pyramid_ms": float(ms_p), "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
                          "walked_all_levels": float((lr == 2).mean()), "tracked_fraction": tracked,
                          "jobs_left_to_general_kernel": deferred.value, "parity": parity,
+                         "walk_lds_bytes": args.prod_walk_lds or 7680, "walk_chunks": bool(args.prod_walk_lds),
                          "one_frame": {"features": nfeat, "ms": float(lat), "ms_min": lat.fastest,
                                        "note": "launch to completion of one frame's walks (one wavefront each) between HIP events"}})
+    capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 0))
+    capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 7680))      # back to the defaults
     pyr.close()
     return out
 

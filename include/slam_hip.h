@@ -64,6 +64,13 @@ int slam_hip_set_match_lds(slam_ctx* ctx, int bytes);
  * templates beyond about 22x22 at full resolution (31x31 templates in 17x17 windows need 10240: 16 walks per CU).  Results do not
  * depend on it. */
 int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes);
+/* on = 1: the lean point-walk kernel also takes walks whose full-resolution level (stored template, every cell) does
+ * not fit the budget above whole: the template is then searched in chunks of rows, the sums of all cells running on
+ * in LDS (the reference's live shape, 81x81 descriptors in 24x24 windows, matching.cpp:243-250 with feature.cpp:133-139:
+ * 15360 bytes and on = 1).  A build of the kernel with more registers: leave it off (the default) for small templates.
+ * The entry points that take a host job table pick budget and build themselves unless this or slam_hip_set_walk_lds
+ * was called.  Results do not depend on it. */
+int slam_hip_set_walk_chunks(slam_ctx* ctx, int on);
 /* Text of the last error on ctx (or of the last failed slam_hip_create when ctx is NULL). */
 const char* slam_hip_last_error_string(const slam_ctx* ctx);
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "slam_hip_synchronize": (C.c_int, [_P]),
     "slam_hip_set_match_lds": (C.c_int, [_P, C.c_int]),
     "slam_hip_set_walk_lds": (C.c_int, [_P, C.c_int]),
+    "slam_hip_set_walk_chunks": (C.c_int, [_P, C.c_int]),
     "slam_hip_last_error_string": (C.c_char_p, [_P]),
     "slam_hip_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "slam_hip_free": (C.c_int, [_P, _P]),

@@ -51,6 +51,8 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) { c->lean_lds_bytes = atoi(wk) * 1024; c->lean_lds_user = 1; }
     const char* wb = getenv("SLAM_HIP_WALK_LDS_BYTES");
     if (wb && atoi(wb) >= 4096 && atoi(wb) <= 65536) { c->lean_lds_bytes = atoi(wb) & ~63; c->lean_lds_user = 1; }
+    const char* wc = getenv("SLAM_HIP_WALK_CHUNKS");
+    if (wc && (wc[0] == '0' || wc[0] == '1')) c->walk_chunks = wc[0] - '0';
     const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");
     if (sk && atoi(sk) >= 4 && atoi(sk) <= 64) c->lean_match_lds_bytes = atoi(sk) * 1024;
     const char* sb = getenv("SLAM_HIP_SEARCH_LDS_BYTES");
@@ -113,6 +115,14 @@ extern "C" int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes) {
         return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_walk_lds: %d not a multiple of 64 in [4096, 65536]", bytes);
     ctx->lean_lds_bytes = bytes;
     ctx->lean_lds_user = 1;
+    return SLAM_HIP_OK;
+}
+
+extern "C" int slam_hip_set_walk_chunks(slam_ctx* ctx, int on) {
+    if (!ctx) return SLAM_HIP_EINVAL;
+    if (on != 0 && on != 1) return slam_set_error(ctx, SLAM_HIP_EINVAL, "set_walk_chunks: %d is neither 0 nor 1", on);
+    ctx->walk_chunks = on;
+    ctx->lean_lds_user = 1;            // the caller picks budget and kernel: no sizing per launch
     return SLAM_HIP_OK;
 }
 

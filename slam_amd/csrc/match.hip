@@ -484,6 +484,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
 // interior window small enough for lean_level (match_lean.h).  A job it does not cover - checked level by level, as
 // the windows depend on the results - is appended to the queue and walked again from the start by track_kernel;
 // nothing is written to `out` for it here.
+template <bool CHUNKS>
 __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_track_job& job, const uint8_t* __restrict__ blob,
                                           unsigned long long blob_bytes, lds_u8* lds, int lds_total, slam_track_result& r) {
     STAMP_DECL;
@@ -535,7 +536,9 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
             if (coarse_area && q == nlev - 1) { aw = job.aw; ah = job.ah; }
             const int step = q == 0 ? 1 : job.stride;
             const int nx = step == 1 ? aw : small_div(aw + step - 1, step), ny = step == 1 ? ah : small_div(ah + step - 1, step);
-            fits = aw >= 1 && ah >= 1 && aw <= 255 && ah <= 255 && lean_need(lvl_t, oth, aw, ah, step, nx, ny, sub != 1.f) <= lds_total;
+            fits = aw >= 1 && ah >= 1 && aw <= 255 && ah <= 255 &&
+                   (CHUNKS ? lean_plan(lvl_t, oth, aw, ah, step, nx, ny, sub != 1.f, true, lds_total).bh > 0
+                           : lean_need(lvl_t, oth, aw, ah, step, nx, ny, sub != 1.f) <= lds_total);
         }
         if (__ballot(!fits) != 0ull) { LEAN_REJECT(13); return false; }
     }
@@ -579,7 +582,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
             LEAN_REJECT(12 + 1000 * i); return false;
         }
         // feature.cpp:151-152: the level that ends the walk also reports the sub-pixel fit
-        const LeanOut o = lean_level<false>(L, lds, lds_total, i == 0, stop_below STAMP_PASS);
+        const LeanOut o = lean_level<false, CHUNKS>(L, lds, lds_total, i == 0, stop_below STAMP_PASS);
         if (!o.ok) return false;
         levels_run++;
         response = o.response; sdx = o.dx; sdy = o.dy;
@@ -593,6 +596,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
     return true;
 }
 
+template <bool CHUNKS>
 __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(sla
     if (j >= njobs) return;
     const slam_track_job job = jobs[j];
     slam_track_result r;
-    const bool done = lean_walk(pyr, job, blob, blob_bytes, lds, lds_total, r);
+    const bool done = lean_walk<CHUNKS>(pyr, job, blob, blob_bytes, lds, lds_total, r);
     if (threadIdx.x == 0) {
         if (done) out[j] = r;
         else queue_put(queue, j);
@@ -989,7 +993,7 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
     if (njobs == 0) return SLAM_HIP_OK;
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (ctx->force_direct || ctx->no_lean) {               // diagnostic settings: every job through the general kernel
-        ctx->lean_lds_once = 0;
+        ctx->lean_lds_once = 0; ctx->walk_chunks_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
                            ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr);
@@ -997,24 +1001,30 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
         return SLAM_HIP_OK;
     }
     int rc2 = slam_queue_reserve(ctx, njobs);
-    if (rc2 != SLAM_HIP_OK) { ctx->lean_lds_once = 0; return rc2; }
+    if (rc2 != SLAM_HIP_OK) { ctx->lean_lds_once = 0; ctx->walk_chunks_once = 0; return rc2; }
     ctx->queue_last = 0;
     return slam_launch_track(ctx, pyr, d_jobs, njobs, d_blob, blob_bytes, d_out, ctx->d_queue, false);
 }
 
 // The entry points that take their job table from the host see the shapes before the launch: they size the lean walk
 // kernel's LDS to the largest need among the walks it could take (the host-side replica of lean_walk's fit check;
-// sizing only - the device decides), within [default, 24 KB], for that launch alone.  A budget set by the caller
-// (slam_hip_set_walk_lds, SLAM_HIP_WALK_LDS_KB) is left alone.
+// sizing only - the device decides), within [default, 24 KB], for that launch alone.  Walks with a level beyond 24 KB
+// that the kernel's other build can take in blocks of cell rows and chunks of template rows (lean_plan) select that
+// build, with the smallest budget in whole granules at which every chunk has SLAM_AUTO_CHUNK_ROWS rows or more.  A
+// budget or build set by the caller (slam_hip_set_walk_lds, slam_hip_set_walk_chunks, SLAM_HIP_WALK_LDS_KB) is left alone.
+#define SLAM_AUTO_CHUNK_ROWS 10
 void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs) {
     ctx->lean_lds_once = 0;
+    ctx->walk_chunks_once = 0;
     if (ctx->lean_lds_user || !pyr) return;
     const int nlev = pyr->dev.nlev;
-    int need = 0;
+    struct Shape { int tw, th, aw, ah, step, nx, ny; bool resized; };
+    int need = 0, need_chunked = 0;
     for (int i = 0; i < njobs; i++) {
         const slam_track_job& jb = jobs[i];
         if (jb.projw < 1 || jb.projh < 1 || jb.projw > 255 || jb.projh > 255 || jb.stride < 1 || jb.stride > 1024) continue;
         const bool coarse_area = (jb.flags & SLAM_HIP_TRACK_COARSE_AREA) != 0;
+        Shape sh[SLAM_HIP_MAX_LEVELS];
         int worst = 0;
         for (int q = 0; q < nlev; q++) {
             const slam_level_dev& lv = pyr->dev.lev[q];
@@ -1028,10 +1038,24 @@ void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job
             if (aw < 1 || ah < 1 || aw > 255 || ah > 255) { worst = INT_MAX; break; }
             const int step = q == 0 ? 1 : jb.stride;
             const int nx = (aw + step - 1) / step, ny = (ah + step - 1) / step;
-            worst = std::max(worst, lean_need(tw, th, aw, ah, step, nx, ny, lv.sub != 1.f));
+            sh[q] = Shape{tw, th, aw, ah, step, nx, ny, lv.sub != 1.f};
+            const int nd = lean_need(tw, th, aw, ah, step, nx, ny, lv.sub != 1.f);
+            worst = std::max(worst, nd);
         }
-        if (worst != INT_MAX && worst <= 24576) need = std::max(need, worst);      // larger walks go to the general kernel anyway
+        if (worst == INT_MAX) continue;                    // a shape the lean kernels do not take at any budget
+        if (worst <= 24576) { need = std::max(need, worst); continue; }
+        if (need_chunked >= 24320) continue;
+        for (int b = std::max(need_chunked, ctx->lean_lds_bytes / 1280 * 1280); b <= 24320; b += 1280) {
+            bool all = true;
+            for (int q = 0; q < nlev && all; q++) {
+                const Shape& h = sh[q];
+                const LeanPlan pl = lean_plan(h.tw, h.th, h.aw, h.ah, h.step, h.nx, h.ny, h.resized, true, b);
+                all = pl.bh > 0 && pl.R >= std::min(SLAM_AUTO_CHUNK_ROWS, h.th);
+            }
+            if (all) { need_chunked = std::max(need_chunked, b); break; }
+        }                                                  // (none found: the walk goes to the general kernel)
     }
+    if (need_chunked > 0) { need = std::max(need, need_chunked); ctx->walk_chunks_once = 1; }
     const int rounded = (need + 1279) / 1280 * 1280;        // whole LDS granules (slam_internal.h)
     if (rounded > ctx->lean_lds_bytes) ctx->lean_lds_once = rounded;
 }
@@ -1041,12 +1065,21 @@ void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job
 int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* d_jobs, int njobs, const uint8_t* d_blob,
                       size_t blob_bytes, slam_track_result* d_out, int* queue, bool clear_first) {
     const int lds = ctx->lean_lds_once ? ctx->lean_lds_once : ctx->lean_lds_bytes;      // a host-table entry point may have sized this launch
+    const bool chunks = ctx->walk_chunks_once ? true : ctx->walk_chunks != 0;
     ctx->lean_lds_once = 0;
+    ctx->walk_chunks_once = 0;
     // a queue shared by every context of the device (the no-alloc entry point) is cleared first: another context's
     // failed or overlapping launch must not leave its count or its entries behind
     if (clear_first) SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, (SLAM_DEFER_LIST + (size_t)njobs) * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(track_lean_kernel, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), lds, ctx->stream, pyr->dev, d_jobs, njobs,
-                       d_blob, (unsigned long long)blob_bytes, d_out, lds, queue);
+    // Two builds of the lean kernel: the plain one takes walks whose every level fits the budget whole; the other also
+    // takes full-resolution levels with templates too large for that, in blocks of cell rows and chunks of template rows (lean_plan), at
+    // the price of more registers - the caller, or slam_size_walk_lds for a host job table, picks it for such shapes.
+    if (chunks)
+        hipLaunchKernelGGL(track_lean_kernel<true>, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), lds, ctx->stream, pyr->dev, d_jobs, njobs,
+                           d_blob, (unsigned long long)blob_bytes, d_out, lds, queue);
+    else
+        hipLaunchKernelGGL(track_lean_kernel<false>, dim3(8 * ((njobs + 7) / 8)), dim3(SLAM_WG), lds, ctx->stream, pyr->dev, d_jobs, njobs,
+                           d_blob, (unsigned long long)blob_bytes, d_out, lds, queue);
     SLAM_HIP_CHECK(ctx, hipGetLastError());                // nothing was queued: the counters are still zero
     // enough workgroups to fill the chip if everything was queued, few enough to start and end in microseconds if nothing was
     const int grid = njobs < 4096 ? njobs : 4096;
@@ -1071,7 +1104,7 @@ extern "C" int slam_hip_track_batch_noalloc_d(slam_ctx* ctx, const slam_pyr* pyr
     if (!q) return slam_set_error(ctx, SLAM_HIP_EINVAL, "track_batch_noalloc: no scratch on device %d", ctx->device);
     SLAM_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (ctx->force_direct || ctx->no_lean) {               // diagnostic settings: every job through the general kernel, no queue
-        ctx->lean_lds_once = 0;
+        ctx->lean_lds_once = 0; ctx->walk_chunks_once = 0;
         hipLaunchKernelGGL(track_kernel, dim3(njobs), dim3(SLAM_WG), ctx->match_lds_bytes,
                            ctx->stream, pyr->dev, d_jobs, njobs, d_blob, (unsigned long long)blob_bytes, d_out,
                            ctx->force_direct, ctx->match_lds_bytes, (int*)nullptr);

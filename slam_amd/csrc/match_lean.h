@@ -142,6 +142,68 @@ __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah
     return ((nacc * 8 + 15) & ~15) + cap * 8 + ((lean_mcap(NG, th, true) * 4 + 15) & ~15) + (tile_bytes > raw_bytes ? tile_bytes : raw_bytes);
 }
 
+// How the chunk-capable builds of the kernels (CHUNKS in lean_level) take a search whose accumulators, lists and tile do
+// not fit `budget` bytes at once: the cells in blocks of bh unit rows (tile, sums and scores per block; the first maximum
+// in row-major order carries over), the template in chunks of R rows (lists and tile per chunk - the tile then holds the
+// image rows under these template rows for the block's cells - while the block's sums run on in the accumulators).  Both
+// are equal parts up to rounding.  Of the block counts 1..8 the one with the least staging work is taken (tile entries
+// and template groups staged over the whole search); bh = 0: not covered.  `walk`: the mask array's size rule (lean_mcap).
+#define LEAN_MIN_CHUNK 4
+struct LeanPlan { int bh, R; };
+
+__host__ __device__ __forceinline__ int lean_div(int n, int d) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return small_div(n, d);
+#else
+    return n / d;
+#endif
+}
+
+__host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, int cpu, int rstep, int rows_all, int bh, int R, bool resized, bool walk) {
+    const int NGc = R * G;
+    const int fit_rows = rows_all < 3 ? rows_all : 3;      // the three rows around the peak are summed at once for the fit
+    const int acc = ((bh > fit_rows ? bh : fit_rows) * upr * cpu * 8 + 15) & ~15;
+    const int tile = (((bh - 1) * rstep + R) * tp * 8 + 15) & ~15;
+    const int raw = NGc * 8 + (resized ? (G * 4 + R) * 8 : 0);
+    return acc + lean_cap(NGc) * 8 + ((lean_mcap(NGc, R, walk) * 4 + 15) & ~15) + (tile > raw ? tile : raw);
+}
+
+__host__ __device__ __forceinline__ LeanPlan lean_plan(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized, bool walk, int budget) {
+    LeanPlan best = {0, 0};
+    const int G = (tw + 3) >> 2;
+    const bool strips = step == 1;
+    const int cols = (aw + 3) >> 2;                        // (these builds shift the window to the tile's first byte)
+    const int tp = (cols + G - 1) | 1;
+    const int rows_all = strips ? ah : ny, rstep = strips ? 1 : step, upr = strips ? cols : nx, cpu = strips ? 4 : 1;
+    // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
+    if (tw > 256 || th > 256 || tw * th > 66051 || tp > 64 || nx * ny > 65535 || budget > (1 << 19)) return best;
+    int best_cost = 0x7fffffff, last_bh = 0;
+    for (int nb = 1; nb <= 8; nb++) {
+        const int bh = lean_div(rows_all + nb - 1, nb);
+        if (bh == last_bh) continue;
+        last_bh = bh;
+        if (bh < (rows_all < 3 ? rows_all : 3)) break;
+        int R = th;
+        if (lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, th, resized, walk) > budget) {
+            const int room = budget - lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, 0, resized, walk);
+            const int per_row = G * 8 + (walk ? 12 : G * 4) + tp * 8;      // list entries, mask entries, a tile row
+            if (room < per_row * LEAN_MIN_CHUNK) continue;
+            R = lean_div(room, per_row);
+            if (R > th - 1) R = th - 1;
+            while (R >= LEAN_MIN_CHUNK && lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, R, resized, walk) > budget) R--;   // roundings of the regions
+            if (R < LEAN_MIN_CHUNK) continue;
+            const int n = lean_div(th + R - 1, R);
+            R = lean_div(th + n - 1, n);
+        }
+        const int nch = R == th ? 1 : lean_div(th + R - 1, R);
+        const int nbl = lean_div(rows_all + bh - 1, bh);
+        const int cost = nbl * nch * (((bh - 1) * rstep + R) * tp + R * G * (resized ? 16 : 2) + 64);
+        if (cost < best_cost) { best_cost = cost; best.bh = bh; best.R = R; }
+        if (nb == 1 && R == th) break;                     // everything at once
+    }
+    return best;
+}
+
 // Accumulators of a block of nu units with NC cells each: the {CC, SI} pair of cell k of unit u is pair k * nu + u, so
 // that the lanes of a flush - consecutive units - fall on consecutive pairs (unit-major pairs, 32 bytes apart, met in
 // 4 of the banks only: the flushes then made a third of all LDS cycles of a walk conflict cycles).  Pair of the cell in
@@ -256,7 +318,7 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
 // carries over from block to block).  `refine_*`: also report the sub-pixel offset of the peak (the level that ends a
 // walk does; single searches always do).  Returns ok = false when the search is not covered here (nothing has been
 // written anywhere).
-template <bool SEARCH>
+template <bool SEARCH, bool CHUNKS = false>
 __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, int lds_total, bool refine_always, double refine_below STAMP_ARG) {
     LeanOut out;
     out.ok = false; out.x = 0; out.y = 0; out.response = 0.f; out.dx = 0.f; out.dy = 0.f;
@@ -264,7 +326,11 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const bool mt = SEARCH && L.mt;
     const bool has_mask = !SEARCH || L.mask != nullptr;
     const int G = (L.tw + 3) >> 2, NG = L.th * G;
-    const int o = L.x0 & 3;
+    // Column phase of the window in the tile.  The plain builds stage whole image dwords, so cell x's window starts o + x
+    // bytes into a tile row and a strip may hold cells of two image dwords; the chunk-capable builds shift the bytes
+    // while staging (the tile starts at the window's first byte), which saves the strip a misaligned window needs extra.
+    const int osrc = L.x0 & 3;
+    const int o = CHUNKS ? 0 : osrc;
     const bool strips = L.step == 1;
     const int nx = strips ? L.aw : small_div_u(L.aw + L.step - 1, L.step), ny = strips ? L.ah : small_div_u(L.ah + L.step - 1, L.step);
     const int cols = (o + L.aw + 3) >> 2;                  // dword columns that hold a cell's first pixel
@@ -273,12 +339,22 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int rstep = strips ? 1 : L.step;                 // image rows from one unit row to the next
     const int upr = strips ? cols : nx;                    // units per row
     const int cpu = strips ? 4 : 1;                        // cells per unit
-    const int cap = lean_cap(NG);                          // room for the padding entries and for reads a few entries ahead
-    const int list_bytes = cap * 8, marr_bytes = (lean_mcap(NG, L.th, !SEARCH) * 4 + 15) & ~15;
+    int R = L.th, nchunk = 1;                              // template rows per chunk, chunks (lean_plan)
     int bh = rows_all, nblk = 1;                           // unit rows per block, blocks
-    if (!SEARCH) {
+    if (CHUNKS) {
+        const LeanPlan pl = lean_plan(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized, !SEARCH, lds_total);
+        bh = uni_i32(pl.bh); R = uni_i32(pl.R);
+        if (bh <= 0) { LEAN_REJECT(100); return out; }
+        nblk = small_div_u(rows_all + bh - 1, bh);
+        if (R < L.th) nchunk = small_div_u(L.th + R - 1, R);
+    } else if (!SEARCH) {
         if (lean_need(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized) > lds_total) { LEAN_REJECT(100); return out; }
-    } else {
+    }
+    const bool chunked = CHUNKS && nchunk > 1;
+    const int NGc = R * G;                                 // groups the lists hold at most
+    const int cap = lean_cap(NGc);                         // room for the padding entries and for reads a few entries ahead
+    const int list_bytes = cap * 8, marr_bytes = (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
+    if (SEARCH && !CHUNKS) {
         // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
         if (L.tw > 256 || L.th > 256 || L.tw * L.th > 66051 || tp > 64) { LEAN_REJECT(101); return out; }
         const int raw_bytes = NG * 8 + (L.resized ? (G * 4 + L.th) * 8 : 0);
@@ -302,29 +378,68 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     lds_u32* marr = reinterpret_cast<lds_u32*>(lds + acc_bytes + list_bytes);       // masks of list entries nA1, nA1 + 1, ...: the all-kept part has none
     lds_u8* tile = lds + acc_bytes + list_bytes + marr_bytes;
     lds_u64* raw = reinterpret_cast<lds_u64*>(tile);       // {P0, M} per group in (row, group) order, until the tile is staged
-    lds_u64* taps = raw + NG;
+    lds_u64* taps = raw + NGc;
 
     STAMP(50);
-    __syncthreads();                                       // the previous level's readers of this LDS are done
-
-    // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
     // A template of at most 32 groups (the coarse levels of a walk) is not sorted into the two lists: compacting it
     // costs more instructions than masking every group of so short a list does.
     // (decided here, from sizes alone: the direct search of a few lattice cells further down needs no entry lists either)
     const int dshift = nx * ny <= 4 ? 4 : nx * ny <= 8 ? 3 : nx * ny <= 16 ? 2 : 1;       // 2^dshift lanes per cell
     const bool direct = !SEARCH && !strips && nx * ny <= 32 && ((L.th + (1 << dshift) - 1) >> dshift) * G <= 16 &&
                         L.x0 + (nx - 1) * L.step + 4 * G <= L.w;
-    const bool tiny = direct || NG <= 32;
+    const bool tiny = direct || (NG <= 32 && !chunked);
     unsigned sp_part = 0;
-    int nA = 0, nB = 0;
     const float rG = __builtin_amdgcn_rcpf((float)G);
-    if (!L.resized) {
-        for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+    Norms nm;
+    nm.p2f = 0.f; nm.tn = 0.0;
+    Best b = {-FLT_MAX, INT_MAX};
+    int S = 1, na = 0, nb = 0, nA1 = 0;                     // slices; all-kept and masked entries per slice; first masked entry
+    const float rnx = __builtin_amdgcn_rcpf((float)nx);
+    int r0 = 0, rows_b = rows_all;                          // the block of cell rows whose sums the accumulators hold
+    int u0 = 0, Rc = L.th;                                  // the template rows the lists and the tile hold
+    int lx = 0, ly = 0;
+    float bv = 0.f;
+    // ---- blocks of cell rows, and within a block chunks of template rows: lists where they change, tile, sums; scores
+    //      when a block's sums are complete; after the last block the argmax and, for the fit, the rows around it
+    for (int blk = 0; blk <= nblk; blk++) {
+        if (blk == nblk) {
+            // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The
+            // wave's maximum first, then the smallest cell index among the lanes that hold it (cv::minMaxLoc: first
+            // maximum in row-major order, NaN never wins).
+            const unsigned bkey = wave_max_u32(b.idx != INT_MAX ? __float_as_uint(b.v) + 1u : 0u);
+            const int bidx = (int)wave_min_u32((b.idx != INT_MAX && __float_as_uint(b.v) + 1u == bkey) ? (unsigned)b.idx : 0xFFFFFFFFu);
+            bv = __uint_as_float(bkey - 1u);
+            STAMP(55);
+            // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is
+            // a -1 of the untouched score map or there is none at all: the general kernel knows those cases.
+            if (bkey == 0u) { LEAN_REJECT(3); return out; }
+            lx = bidx & 0xffff; ly = bidx >> 16;
+            out.ok = true;
+            out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
+            out.response = bv;
+            if (!(refine_always || (double)bv < refine_below)) return out;
+            if (!strips) return out;                       // off the lattice the four neighbours are unvisited: no fit
+            if (nblk == 1) break;                          // the sums of the only block are still in place
+            r0 = max(ly - 1, 0); rows_b = min(ly + 1, L.ah - 1) - r0 + 1;
+        } else {
+            r0 = blk * bh; rows_b = min(bh, rows_all - r0);
+        }
+        const int nunits = rows_b * upr;
+      int ch = 0;
+      do {                                                  // (one pass unless the template is taken in chunks)
+        if (chunked) { u0 = ch * R; Rc = min(R, L.th - u0); }
+      if ((blk == 0 && ch == 0) || chunked) {
+        __syncthreads();                                   // the previous level's, block's or chunk's readers of this LDS are done
+        // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
+        const int NGb = Rc * G;                            // groups of these template rows
+        int nA = 0, nB = 0;
+        if (!L.resized) {
+        for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
             const int i = i0 + lane;
             unsigned P0 = 0, M = 0;
-            if (i < NG) {
+            if (i < NGb) {
                 const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G;
-                const long long so = (long long)u * L.srcw + gq * 4;
+                const long long so = (long long)(u0 + u) * L.srcw + gq * 4;
                 const unsigned P = load4(L.patch + so, L.limit);
                 const unsigned Mraw = has_mask ? load4(L.mask + so, L.limit) : 0x01010101u;
                 const int nb = min(4, L.tw - gq * 4);
@@ -333,7 +448,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 M = ((nz >> 7) * 0xFFu) & keep;
                 P0 = P & M;
                 raw[i] = ((unsigned long long)M << 32) | P0;
-                sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
+                if (!CHUNKS || blk == 0) sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
             }
             nA += __builtin_popcountll(__ballot(M == 0xFFFFFFFFu));
             nB += __builtin_popcountll(__ballot(M != 0u && M != 0xFFFFFFFFu));
@@ -341,17 +456,17 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     } else {
         // cv::resize of template and mask on the fly (feature.cpp:130-131): tap tables first, then one pixel per lane
         // and step - 4 source bytes of the patch, 4 of the mask, fixed-point blend - into the raw bytes
-        const int wpx = G * 4, ntap = wpx + L.th;
+        const int wpx = G * 4, ntap = wpx + Rc;
         for (int i = lane; i < ntap; i += SLAM_WG) {
             int so, c0, c1;
             if (i < wpx) resize_tap(min(i, L.tw - 1), L.scx, L.srcw, true, so, c0, c1);
-            else resize_tap(i - wpx, L.scy, L.srch, false, so, c0, c1);
+            else resize_tap(u0 + i - wpx, L.scy, L.srch, false, so, c0, c1);
             taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)so;
         }
         __syncthreads();
         lds_u8* rb = reinterpret_cast<lds_u8*>(raw);
         const float rw = __builtin_amdgcn_rcpf((float)wpx);
-        const int n = L.th * wpx;
+        const int n = Rc * wpx;
         for (int i0 = 0; i0 < n; i0 += SLAM_WG) {
             const int ii = i0 + lane;
             const bool live = ii < n;
@@ -367,23 +482,22 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             unsigned p = (unsigned)resize_blend(spx, a0, a1, b0, b1, false) * m;
             if (pad) { p = 0; m = 0; }
             if (live) {
-                sp_part += p * p;
+                if (!CHUNKS || blk == 0) sp_part += p * p;
                 rb[eo] = (unsigned char)p;
                 rb[eo + 4] = m ? 0xFF : 0x00;
             }
         }
         __syncthreads();
         if (!tiny)
-            for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+            for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
                 const int i = i0 + lane;
-                const unsigned M = i < NG ? (unsigned)(raw[i] >> 32) : 0u;
+                const unsigned M = i < NGb ? (unsigned)(raw[i] >> 32) : 0u;
                 nA += __builtin_popcountll(__ballot(M == 0xFFFFFFFFu));
                 nB += __builtin_popcountll(__ballot(M != 0u && M != 0xFFFFFFFFu));
             }
     }
     if (tiny) { nA = 0; nB = NG; }
-    const unsigned spfull = wave_sum_u32(sp_part);
-    const Norms nm = make_norms(spfull);
+    if (!CHUNKS || (blk == 0 && ch == nchunk - 1)) nm = make_norms(wave_sum_u32(sp_part));       // |P0|^2 of the whole template
     STAMP(51);
 
     // ---- a handful of lattice cells under a small template (the coarse levels of a walk) --------------------------------
@@ -393,12 +507,12 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     // sums of a cell meet by DPP butterflies, and the cell's first lane scores it.  Same integer sums, same formula, same
     // argmax rule as below.  (The last group's dword may reach up to 3 bytes past the template: it must stay inside
     // the image row.  Off the lattice there is no sub-pixel fit - the neighbours are unvisited - so none is needed here.)
-    Best b = {-FLT_MAX, INT_MAX};
-    const LeanSlices lsl = direct ? LeanSlices{1, 0, 0} : lean_pick_slices(bh * upr, nA, nB, strips);
-    const int S = lsl.S, na = lsl.na, nA1 = na * S;           // all-kept entries per slice; the rest of them joins the masked part
-    const int nb = lsl.nb, nB1 = nb * S;
+    const LeanSlices lsl = direct ? LeanSlices{1, 0, 0} : lean_pick_slices(chunked ? nunits : bh * upr, nA, nB, strips);
+    S = lsl.S; na = lsl.na; nA1 = na * S;                   // all-kept entries per slice; the rest of them joins the masked part
+    nb = lsl.nb;
+    const int nB1 = nb * S;
     // a mask with more partly kept groups than a warped quadrilateral has (never true for single searches)
-    if (!SEARCH && !direct && nB1 + 2 > lean_mcap(NG, L.th, true)) { LEAN_REJECT(4); return out; }
+    if (!SEARCH && !direct && nB1 + 2 > lean_mcap(NGc, R, true)) { LEAN_REJECT(4); return out; }
     __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
     if (direct) {
         const int ncell = nx * ny, pshift = dshift;
@@ -439,6 +553,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         }
         if (live && part == 0 && !(L.amask && L.amask[y * L.aw + x] == 0))
             best_update(b, score_f32_n(cc, si, nm.p2f), (y << 16) | x);
+        break;                                              // straight to the argmax
     } else if (tiny) {                                      // every group a masked entry, in template order
         if (lane < NG) {
             const unsigned long long r = raw[lane];
@@ -449,10 +564,10 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         for (int p = NG + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p] = 0u; }
     } else {
         int baseA = 0, baseB = nA;
-        for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+        for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
             const int i = i0 + lane;
             unsigned P0 = 0, M = 0;
-            if (i < NG) { const unsigned long long r = raw[i]; P0 = (unsigned)r; M = (unsigned)(r >> 32); }
+            if (i < NGb) { const unsigned long long r = raw[i]; P0 = (unsigned)r; M = (unsigned)(r >> 32); }
             const bool isA = M == 0xFFFFFFFFu, isB = M != 0u && !isA;
             const unsigned long long ba = __ballot(isA), bb = __ballot(isB);
             const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G;
@@ -466,40 +581,12 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         for (int p = nA + nB + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p - nA1] = 0u; }   // padding: adds nothing
     }
     STAMP(52);
-
-    // ---- blocks of rows: tile, sums, scores; after the last one the argmax and, for the fit, the rows around it ----
-    const float rnx = __builtin_amdgcn_rcpf((float)nx);
-    int r0 = 0, rows_b = rows_all;                          // the block whose sums the accumulators hold
-    int lx = 0, ly = 0;
-    float bv = 0.f;
-    for (int blk = direct ? nblk : 0; blk <= nblk; blk++) {
-        if (blk == nblk) {
-            // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The
-            // wave's maximum first, then the smallest cell index among the lanes that hold it (cv::minMaxLoc: first
-            // maximum in row-major order, NaN never wins).
-            const unsigned bkey = wave_max_u32(b.idx != INT_MAX ? __float_as_uint(b.v) + 1u : 0u);
-            const int bidx = (int)wave_min_u32((b.idx != INT_MAX && __float_as_uint(b.v) + 1u == bkey) ? (unsigned)b.idx : 0xFFFFFFFFu);
-            bv = __uint_as_float(bkey - 1u);
-            STAMP(55);
-            // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is
-            // a -1 of the untouched score map or there is none at all: the general kernel knows those cases.
-            if (bkey == 0u) { LEAN_REJECT(3); return out; }
-            lx = bidx & 0xffff; ly = bidx >> 16;
-            out.ok = true;
-            out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
-            out.response = bv;
-            if (!(refine_always || (double)bv < refine_below)) return out;
-            if (!strips) return out;                       // off the lattice the four neighbours are unvisited: no fit
-            if (nblk == 1) break;                          // the sums of the only block are still in place
-            r0 = max(ly - 1, 0); rows_b = min(ly + 1, L.ah - 1) - r0 + 1;
-        } else {
-            r0 = blk * bh; rows_b = min(bh, rows_all - r0);
-        }
-        const int nunits = rows_b * upr;
+      }
         __syncthreads();                                    // lists complete; the previous block's readers of tile and sums done
-        for (int i = lane; i < nunits * cpu * 2; i += SLAM_WG) acc[i] = 0;
-        {   // image tile: byte windows W0 and W3 of every dword position
-            const int trows = (rows_b - 1) * rstep + L.th;
+        if (ch == 0)
+            for (int i = lane; i < nunits * cpu * 2; i += SLAM_WG) acc[i] = 0;
+        {   // image tile: byte windows W0 and W3 of every dword position, for the image rows under template rows u0 .. u0 + Rc - 1
+            const int trows = (rows_b - 1) * rstep + Rc;
             const int lg = 32 - __builtin_clz((unsigned)tp);   // 2^lg > tp lanes per tile row
             const int c = lane & ((1 << lg) - 1), lr = lane >> lg, rpp = SLAM_WG >> lg;
             if (c < tp) {
@@ -507,22 +594,30 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 // columns (whose sums are dropped or masked to zero), and rows past the tile by nobody: such loads are
                 // clamped onto valid dwords instead of being predicated.
                 const unsigned lastd = (unsigned)(L.w >> 2) - 1u;
-                const unsigned dcol = (unsigned)((L.x0 - o) >> 2) + (unsigned)c;
-                const unsigned g0 = min(dcol, lastd) * 4u, g1 = min(dcol + 1u, lastd) * 4u;
-                const uint8_t* src = L.im + (unsigned long long)(L.y0 + r0 * rstep) * L.ipitch;
+                const unsigned dcol = (unsigned)((L.x0 - osrc) >> 2) + (unsigned)c;
+                const unsigned g0 = min(dcol, lastd) * 4u, g1 = min(dcol + 1u, lastd) * 4u, g2 = min(dcol + 2u, lastd) * 4u;
+                const bool low = osrc == 0;                 // bytes 3..6 from the window's start begin in the first dword
+                const uint8_t* src = L.im + (unsigned long long)(L.y0 + r0 * rstep + u0) * L.ipitch;
                 const int nit = (trows + rpp - 1) >> (6 - lg);   // wave-uniform
                 for (int it = 0; it < nit; it += 4) {
-                    unsigned d0[4], d1[4], ro[4];
+                    unsigned d0[4], d1[4], d2[4], ro[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         ro[q] = (unsigned)min(lr + (it + q) * rpp, trows - 1);
                         d0[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g0);
                         d1[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g1);
+                        if (CHUNKS) d2[q] = *reinterpret_cast<const unsigned*>(src + ro[q] * L.ipitch + g2);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const unsigned w3 = __builtin_amdgcn_alignbyte(d1[q], d0[q], 3);
-                        *reinterpret_cast<lds_u64*>(tile + (ro[q] * (unsigned)tp + (unsigned)c) * 8u) = ((unsigned long long)w3 << 32) | d0[q];
+                        unsigned w0 = d0[q], w3;
+                        if (CHUNKS) {
+                            w0 = __builtin_amdgcn_alignbyte(d1[q], d0[q], (unsigned)osrc);
+                            w3 = __builtin_amdgcn_alignbyte(low ? d1[q] : d2[q], low ? d0[q] : d1[q], (unsigned)(osrc + 3) & 3u);
+                        } else {
+                            w3 = __builtin_amdgcn_alignbyte(d1[q], d0[q], 3);
+                        }
+                        *reinterpret_cast<lds_u64*>(tile + (ro[q] * (unsigned)tp + (unsigned)c) * 8u) = ((unsigned long long)w3 << 32) | w0;
                     }
                 }
             }
@@ -533,6 +628,9 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         else lean_accumulate<1>(tile, list, marr, acc, nunits, S, na, nb, nA1, nx, tp, o, L.step);
         __syncthreads();
         STAMP(54);
+        ch++;
+      } while (CHUNKS && ch < nchunk);
+        if (direct) { blk = nblk - 1; continue; }
         if (blk == nblk) break;                            // the rows around the peak: no scores, the fit reads the sums
 
         // ---- scores of the block's cells ---------------------------------------------------------------------------

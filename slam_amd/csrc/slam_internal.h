@@ -27,6 +27,8 @@ struct slam_ctx {
     int lean_lds_bytes = 7680;         // LDS per job of the lean walk kernel: 6 granules, 21 jobs per CU
     int lean_lds_user = 0;             // set by the caller (slam_hip_set_walk_lds, SLAM_HIP_WALK_LDS_KB): never sized automatically
     int lean_lds_once = 0;             // budget of the next walk launch only (slam_size_walk_lds), 0 = lean_lds_bytes
+    int walk_chunks = 0;               // lean walk kernel built with template chunks (slam_hip_set_walk_chunks, SLAM_HIP_WALK_CHUNKS)
+    int walk_chunks_once = 0;          // the same for the next walk launch only (slam_size_walk_lds)
     int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: walks and searches skip the lean kernels (cross-check of them)
     int lean_match_lds_bytes = 7680;   // LDS per job of the lean single-search kernel: 6 granules; its registers allow 20 jobs per CU (SLAM_HIP_SEARCH_LDS_KB / _BYTES)
     int lean_match_min_jobs = 64;      // smaller batches of single searches take the general kernel alone (SLAM_HIP_SEARCH_LEAN_MIN)
