@@ -51,6 +51,10 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     if (wk && atoi(wk) >= 4 && atoi(wk) <= 64) { c->lean_lds_bytes = atoi(wk) * 1024; c->lean_lds_user = 1; }
     const char* wb = getenv("SLAM_HIP_WALK_LDS_BYTES");
     if (wb && atoi(wb) >= 4096 && atoi(wb) <= 65536) { c->lean_lds_bytes = atoi(wb) & ~63; c->lean_lds_user = 1; }
+    const char* ll = getenv("SLAM_HIP_LINE_LEAN_LDS_BYTES");
+    if (ll && atoi(ll) >= 4096 && atoi(ll) <= 65536) c->line_lean_lds_bytes = atoi(ll) & ~63;
+    const char* lm = getenv("SLAM_HIP_LINE_LEAN_MIN");
+    if (lm && atoi(lm) >= 1) c->line_lean_min_jobs = atoi(lm);
     const char* wc = getenv("SLAM_HIP_WALK_CHUNKS");
     if (wc && (wc[0] == '0' || wc[0] == '1')) c->walk_chunks = wc[0] - '0';
     const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");

@@ -684,6 +684,58 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE) void line_coarse_kern
     if (threadIdx.x == 0) bands[(size_t)j * nb + band] = out;
 }
 
+// The coarsest search of every line of a large batch (lineFeature.cpp:124-127) through lean_level's build with blocks of
+// cell rows and chunks of template rows: one wavefront per line, the same band record as line_coarse_kernel (one band:
+// the whole area).  Covered: areas whose candidate patches all lie inside the image (every cell is then scored by
+// matchTemplate's rule whatever the stride or the area mask, matching.cpp:151-153); any other area, and any search
+// lean_level turns away, is marked invalid and searched by line_track_kernel itself.
+#ifndef SLAM_MIN_WAVES_LINE_LEAN
+#define SLAM_MIN_WAVES_LINE_LEAN 4
+#endif
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE_LEAN) void line_lean_coarse_kernel(slam_pyr_dev pyr, const slam_line_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob, unsigned long long blob_bytes,
+                                                        LineBand* __restrict__ bands, int lds_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const slam_line_job job = jobs[j];
+    LineBand out = {0, 0, -1.f, 0};
+    STAMP_DECL;
+    if (line_job_ok(pyr, job, blob_bytes) && job.dw <= 255 && job.dh <= 255 && job.aw <= 255 && job.ah <= 255) {
+        const int i = pyr.nlev - 1;
+        float sub = 1.f; int lw = 0, lh = 0; long long lp = 0, ls = 0; const uint8_t* ld = nullptr;
+#pragma unroll
+        for (int l = 0; l < SLAM_HIP_MAX_LEVELS; l++)
+            if (l == i) { sub = pyr.lev[l].sub; lw = pyr.lev[l].w; lh = pyr.lev[l].h; lp = pyr.lev[l].pitch; ls = pyr.lev[l].frame_stride; ld = pyr.lev[l].data; }
+        const float areaRes = __fdiv_rn(1.f, sub);                                  // lineFeature.cpp:30
+        LeanLevel L;
+        L.tw = __builtin_amdgcn_readfirstlane(round_f2i(__fmul_rn((float)job.dw, areaRes)));   // lineFeature.cpp:124
+        L.th = __builtin_amdgcn_readfirstlane(round_f2i(__fmul_rn((float)job.dh, areaRes)));
+        if (L.tw > 0 && L.th > 0 && L.tw <= 255 && L.th <= 255) {
+            L.im = ld + (long long)job.frame * ls;
+            L.ipitch = (unsigned)lp; L.w = lw; L.h = lh;
+            L.srcw = job.dw; L.srch = job.dh;
+            L.resized = !(L.tw == job.dw && L.th == job.dh);  // cv::resize to the same size copies the image
+            L.scx = 1.0; L.scy = 1.0;
+            if (L.resized) { L.scx = resize_scale(job.dw, L.tw); L.scy = resize_scale(job.dh, L.th); }
+            L.patch = blob + job.desc_off; L.mask = nullptr; L.limit = blob + blob_bytes;
+            L.mt = true;
+            L.x0 = job.ax - L.tw / 2; L.y0 = job.ay - L.th / 2;                       // matching.cpp:38-39
+            L.aw = job.aw; L.ah = job.ah;
+            L.step = 1;
+            L.amask = nullptr;
+            const bool ok = L.x0 >= 0 && L.y0 >= 0 && L.x0 + L.aw + L.tw - 1 <= L.w && L.y0 + L.ah + L.th - 1 <= L.h && lp <= 0x7fffffffLL &&
+                            ((reinterpret_cast<unsigned long long>(L.im) | (unsigned long long)lp) & 3ull) == 0;
+            if (ok) {
+                const LeanOut o = lean_level<true, true>(L, lds, lds_total, false, 0.0 STAMP_PASS);
+                if (o.ok) { out.x = o.x; out.y = o.y; out.response = o.response; out.valid = 1; }
+            }
+        }
+    }
+    if (threadIdx.x == 0) bands[j] = out;
+}
+
 // The searches of SLAM::LineFeature::track (lineFeature.cpp:120-165) for one line feature: the
 // descriptor resized to the coarsest level and searched without a patch mask inside the area mask
 // (lineFeature.cpp:124-127), then, while the response stays above 0.67*threshold, each finer level in
@@ -750,9 +802,10 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE) void line_track_kerne
         int mx = 0, my = 0;
         sdx = 0.f; sdy = 0.f;
         levels_run++;
-        // the coarsest level of a small batch: searched in bands by line_coarse_kernel (all bands valid, or none)
+        // the coarsest level searched beforehand: in bands by line_coarse_kernel (a small batch; all bands valid, or none)
+        // or whole by line_lean_coarse_kernel (one band)
         bool banded = false;
-        if (coarsest && bands && nb > 1 && !g.reject) {
+        if (coarsest && bands && !g.reject) {
             const LineBand* bj = bands + (size_t)j * nb;
             banded = true;
             LineBand best = {0, 0, -FLT_MAX, 0};
@@ -1161,8 +1214,10 @@ extern "C" int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, c
     // 3072 at once) has its coarsest searches cut into bands of rows, up to 8 per line (line_coarse_kernel).
     int nb = ctx->line_bands > 0 ? ctx->line_bands : 3072 / njobs;
     nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+    // A large batch has them searched by the lean core first (line_lean_coarse_kernel): one band per line.
+    const bool lean = nb == 1 && !ctx->force_direct && !ctx->no_lean && njobs >= ctx->line_lean_min_jobs;
     LineBand* d_bands = nullptr;
-    if (nb > 1) {
+    if (nb > 1 || lean) {
         const size_t need = (size_t)njobs * nb * sizeof(LineBand);
         if (need > ctx->bands_bytes) {                         // grown on demand, like the walk queue
             SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1176,7 +1231,11 @@ extern "C" int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, c
         }
         d_bands = (LineBand*)ctx->d_bands;
     }
-    if (nb > 1) {
+    if (lean && d_bands) {
+        hipLaunchKernelGGL(line_lean_coarse_kernel, dim3(njobs), dim3(SLAM_WG), ctx->line_lean_lds_bytes, ctx->stream, pyr->dev, d_jobs,
+                           njobs, d_blob, (unsigned long long)blob_bytes, d_bands, ctx->line_lean_lds_bytes);
+        SLAM_HIP_CHECK(ctx, hipGetLastError());
+    } else if (nb > 1) {
         hipLaunchKernelGGL(line_coarse_kernel, dim3(njobs, nb), dim3(SLAM_WG), ctx->line_lds_bytes, ctx->stream, pyr->dev, d_jobs,
                            njobs, d_blob, (unsigned long long)blob_bytes, d_bands, nb, ctx->force_direct, ctx->line_lds_bytes);
         SLAM_HIP_CHECK(ctx, hipGetLastError());

@@ -59,6 +59,17 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// inclusive prefix sum over the lanes (Hillis-Steele inside the rows of 16 lanes, then the row totals)
+__device__ __forceinline__ unsigned wave_scan_u32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_ROW_SHR(8), 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_BCAST15, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, SLAM_DPP_BCAST31, 0xc, 0xf, false);
+    return v;
+}
+
 struct LeanLevel {           // wave-uniform description of one level's search
     const uint8_t* im;       // level image of the job's frame (4-byte aligned, pitch a multiple of 4)
     unsigned ipitch;
@@ -151,6 +162,11 @@ __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah
 #define LEAN_MIN_CHUNK 4
 struct LeanPlan { int bh, R; };
 
+// dwords per template row of the resident P0 array of lean_level's box mode: rows of three groups and more start on
+// 16-byte boundaries (four groups' dwords are read at once); with fewer the rows stay packed, which keeps the in-place
+// move from the staged {P0, M} pairs (8 bytes a group) behind its own reads
+__host__ __device__ __forceinline__ int lean_pc_pitch(int G) { return G >= 3 ? (G + 3) & ~3 : G; }
+
 __host__ __device__ __forceinline__ int lean_div(int n, int d) {
 #ifdef __HIP_DEVICE_COMPILE__
     return small_div(n, d);
@@ -159,16 +175,26 @@ __host__ __device__ __forceinline__ int lean_div(int n, int d) {
 #endif
 }
 
-__host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, int cpu, int rstep, int rows_all, int bh, int R, bool resized, bool walk) {
+__host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, int cpu, int rstep, int rows_all, int bh, int R, bool resized, bool walk,
+                                                        int th, bool box) {
     const int NGc = R * G;
     const int fit_rows = rows_all < 3 ? rows_all : 3;      // the three rows around the peak are summed at once for the fit
     const int acc = ((bh > fit_rows ? bh : fit_rows) * upr * cpu * 8 + 15) & ~15;
-    const int tile = (((bh - 1) * rstep + R) * tp * 8 + 15) & ~15;
+    int tile = (((bh - 1) * rstep + R) * tp * 8 + 15) & ~15;
+    if (tile < 2 * SLAM_WG * 4) tile = 2 * SLAM_WG * 4;    // the box sums' prefix array lives there before the tile
+    if (box) {
+        // no lists: the whole template's P0 dwords stay resident, staged (8 bytes a group, taps behind them) where the
+        // tile goes afterwards
+        const int NG = th * G, keep = (th * lean_pc_pitch(G) * 4 + 15) & ~15;
+        const int stage = NG * 8 + (resized ? (G * 4 + th) * 8 : 0);
+        return acc + (keep + tile > stage ? keep + tile : stage);
+    }
     const int raw = NGc * 8 + (resized ? (G * 4 + R) * 8 : 0);
     return acc + lean_cap(NGc) * 8 + ((lean_mcap(NGc, R, walk) * 4 + 15) & ~15) + (tile > raw ? tile : raw);
 }
 
-__host__ __device__ __forceinline__ LeanPlan lean_plan(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized, bool walk, int budget) {
+__host__ __device__ __forceinline__ LeanPlan lean_plan(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized, bool walk, int budget,
+                                                       bool box = false) {
     LeanPlan best = {0, 0};
     const int G = (tw + 3) >> 2;
     const bool strips = step == 1;
@@ -184,20 +210,20 @@ __host__ __device__ __forceinline__ LeanPlan lean_plan(int tw, int th, int aw, i
         last_bh = bh;
         if (bh < (rows_all < 3 ? rows_all : 3)) break;
         int R = th;
-        if (lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, th, resized, walk) > budget) {
-            const int room = budget - lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, 0, resized, walk);
-            const int per_row = G * 8 + (walk ? 12 : G * 4) + tp * 8;      // list entries, mask entries, a tile row
+        if (lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, th, resized, walk, th, box) > budget) {
+            const int room = budget - lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, 0, resized, walk, th, box);
+            const int per_row = box ? tp * 8 : G * 8 + (walk ? 12 : G * 4) + tp * 8;      // list entries, mask entries, a tile row
             if (room < per_row * LEAN_MIN_CHUNK) continue;
             R = lean_div(room, per_row);
             if (R > th - 1) R = th - 1;
-            while (R >= LEAN_MIN_CHUNK && lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, R, resized, walk) > budget) R--;   // roundings of the regions
+            while (R >= LEAN_MIN_CHUNK && lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, R, resized, walk, th, box) > budget) R--;   // roundings of the regions
             if (R < LEAN_MIN_CHUNK) continue;
             const int n = lean_div(th + R - 1, R);
             R = lean_div(th + n - 1, n);
         }
         const int nch = R == th ? 1 : lean_div(th + R - 1, R);
         const int nbl = lean_div(rows_all + bh - 1, bh);
-        const int cost = nbl * nch * (((bh - 1) * rstep + R) * tp + R * G * (resized ? 16 : 2) + 64);
+        const int cost = nbl * nch * (((bh - 1) * rstep + R) * tp + (box ? 0 : R * G * (resized ? 16 : 2)) + 64);
         if (cost < best_cost) { best_cost = cost; best.bh = bh; best.R = R; }
         if (nb == 1 && R == th) break;                     // everything at once
     }
@@ -218,9 +244,22 @@ __device__ __forceinline__ float lean_score(const lds_u32* acc, int ai, const No
 
 // One entry of the lists for the NC cells of a unit: cc += <window, P0>, si += <window & M, window & M>.  A tile entry
 // holds the byte windows W0 (bytes 0..3 from its position) and W3 (bytes 3..6); W1 and W2 are picked out of the two.
-template <int NC, bool MASKED>
+template <int NC, bool MASKED, bool SI = true>
 __device__ __forceinline__ void lean_step(const lds_u8* wp, unsigned P0, unsigned M, unsigned sel, unsigned (&cc)[NC], unsigned (&si)[NC]) {
-    if (NC == 4) {
+    if (!SI) {
+        // numerators only: the window energies come from box sums of the squared image (lean_level)
+        const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
+        const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
+        if (NC == 4) {
+            const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
+            cc[0] = __builtin_amdgcn_udot4(w0, P0, cc[0], false);
+            cc[1 % NC] = __builtin_amdgcn_udot4(w1, P0, cc[1 % NC], false);
+            cc[2 % NC] = __builtin_amdgcn_udot4(w2, P0, cc[2 % NC], false);
+            cc[3 % NC] = __builtin_amdgcn_udot4(w3, P0, cc[3 % NC], false);
+        } else {
+            cc[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(w3, w0, sel), P0, cc[0], false);
+        }
+    } else if (NC == 4) {
         const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
         const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
         const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
@@ -251,7 +290,7 @@ __device__ __forceinline__ unsigned lean_window_sel(unsigned k) {
 // slice, so an entry read is one broadcast address and the window reads of a lane group fall on 16-byte tile entries an
 // odd number of entries apart (distinct banks).  Entries are fetched four ahead of their use; the lists are padded so that reading
 // up to four entries past a slice stays inside them.
-template <int NC>
+template <int NC, bool SI = true>
 __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u64* list, const lds_u32* marr, lds_u32* acc,
                                                 int nunits, int S, int na, int nb, int nA1, int div_units, int tp, int o, int step) {
     const int lane = lane_here();
@@ -277,14 +316,14 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
             for (; e + 4 <= na; e += 4) {
                 const unsigned long long c0 = q0, c1 = q1, c2 = q2, c3 = q3;
                 q0 = ea[e + 4]; q1 = ea[e + 5]; q2 = ea[e + 6]; q3 = ea[e + 7];
-                lean_step<NC, false>(tl + (unsigned)(c0 >> 32), (unsigned)c0, 0u, sel, cc, si);
-                lean_step<NC, false>(tl + (unsigned)(c1 >> 32), (unsigned)c1, 0u, sel, cc, si);
-                lean_step<NC, false>(tl + (unsigned)(c2 >> 32), (unsigned)c2, 0u, sel, cc, si);
-                lean_step<NC, false>(tl + (unsigned)(c3 >> 32), (unsigned)c3, 0u, sel, cc, si);
+                lean_step<NC, false, SI>(tl + (unsigned)(c0 >> 32), (unsigned)c0, 0u, sel, cc, si);
+                lean_step<NC, false, SI>(tl + (unsigned)(c1 >> 32), (unsigned)c1, 0u, sel, cc, si);
+                lean_step<NC, false, SI>(tl + (unsigned)(c2 >> 32), (unsigned)c2, 0u, sel, cc, si);
+                lean_step<NC, false, SI>(tl + (unsigned)(c3 >> 32), (unsigned)c3, 0u, sel, cc, si);
             }
-            if (e < na) lean_step<NC, false>(tl + (unsigned)(q0 >> 32), (unsigned)q0, 0u, sel, cc, si);
-            if (e + 1 < na) lean_step<NC, false>(tl + (unsigned)(q1 >> 32), (unsigned)q1, 0u, sel, cc, si);
-            if (e + 2 < na) lean_step<NC, false>(tl + (unsigned)(q2 >> 32), (unsigned)q2, 0u, sel, cc, si);
+            if (e < na) lean_step<NC, false, SI>(tl + (unsigned)(q0 >> 32), (unsigned)q0, 0u, sel, cc, si);
+            if (e + 1 < na) lean_step<NC, false, SI>(tl + (unsigned)(q1 >> 32), (unsigned)q1, 0u, sel, cc, si);
+            if (e + 2 < na) lean_step<NC, false, SI>(tl + (unsigned)(q2 >> 32), (unsigned)q2, 0u, sel, cc, si);
         }
         {   // partly masked groups (and the padding entries, mask 0)
             const lds_u64* eb = list + nA1 + slice * nb;
@@ -296,17 +335,79 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
                 const unsigned long long c0 = q0, c1 = q1;
                 const unsigned k0 = m0, k1 = m1;
                 q0 = eb[e + 2]; q1 = eb[e + 3]; m0 = mb[e + 2]; m1 = mb[e + 3];
-                lean_step<NC, true>(tl + (unsigned)(c0 >> 32), (unsigned)c0, k0, sel, cc, si);
-                lean_step<NC, true>(tl + (unsigned)(c1 >> 32), (unsigned)c1, k1, sel, cc, si);
+                lean_step<NC, SI, SI>(tl + (unsigned)(c0 >> 32), (unsigned)c0, k0, sel, cc, si);
+                lean_step<NC, SI, SI>(tl + (unsigned)(c1 >> 32), (unsigned)c1, k1, sel, cc, si);
             }
-            if (e < nb) lean_step<NC, true>(tl + (unsigned)(q0 >> 32), (unsigned)q0, m0, sel, cc, si);
+            if (e < nb) lean_step<NC, SI, SI>(tl + (unsigned)(q0 >> 32), (unsigned)q0, m0, sel, cc, si);
         }
         if (t0 + lane < ntask) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2 + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (SI) __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2 + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+        }
+    }
+}
+
+// Numerators of a block of strips under rows u0 .. u0 + Rc - 1 of a template without a mask (the box mode of lean_level:
+// no entry lists - `pc` holds the P0 dword of every group of the chunk's rows, row after row).  Tasks are (slice, unit),
+// slice-major; a slice takes the chunk's rows s, s + S, ... and walks their groups in order: one window read, two
+// v_perm and four v_dot4 per group, the group's offset an immediate.
+__device__ __forceinline__ int lean_pick_row_slices(int nunits, int Rc, int G) {
+    int best = 1, best_c = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        constexpr int cand[6] = {1, 2, 3, 4, 6, 8};
+        const int s = cand[q];
+        const int passes = (nunits * s + SLAM_WG - 1) >> 6;
+        const int c = passes * (((Rc + s - 1) / s) * (G * 6 + 4) + 20);
+        if (c < best_c) { best_c = c; best = s; }
+    }
+    return best;
+}
+
+__device__ __forceinline__ void lean_accumulate_rows(const lds_u8* tile, const lds_u32* pc, lds_u32* acc, int nunits, int S, int Rc, int G,
+                                                     int rows, int tp) {
+    const int lane = lane_here();
+    const int ntask = nunits * S;
+    const float rnu = __builtin_amdgcn_rcpf((float)nunits), rdu = __builtin_amdgcn_rcpf((float)rows);
+    for (int t0 = 0; t0 < ntask; t0 += SLAM_WG) {
+        const int task = min(t0 + lane, ntask - 1);        // surplus lanes repeat the last task and do not flush
+        const int slice = (int)(((float)task + 0.5f) * rnu), unit = task - slice * nunits;
+        const int uq = (int)(((float)unit + 0.5f) * rdu), um = unit - uq * rows;      // strip, row (unit = strip * rows + row)
+        const lds_u8* tl = tile + (unsigned)((um + slice) * tp + uq) * 8u;
+        const int Gp = lean_pc_pitch(G);
+        const lds_u32* pr = pc + slice * Gp;
+        unsigned cc[4] = {0u, 0u, 0u, 0u};
+        auto group = [&](unsigned P0, const lds_u8* wp) {
+            const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
+            const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
+            const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
+            cc[0] = __builtin_amdgcn_udot4(w0, P0, cc[0], false);
+            cc[1] = __builtin_amdgcn_udot4(w1, P0, cc[1], false);
+            cc[2] = __builtin_amdgcn_udot4(w2, P0, cc[2], false);
+            cc[3] = __builtin_amdgcn_udot4(w3, P0, cc[3], false);
+        };
+        for (int u = slice; u < Rc; u += S) {
+            int g = 0;
+            for (; g + 4 <= G; g += 4) {                   // the P0 dwords of four groups in one read
+                const v4u32 p4 = *reinterpret_cast<const lds_v4u32*>(pr + g);
+                group(p4.x, tl + g * 8); group(p4.y, tl + g * 8 + 8); group(p4.z, tl + g * 8 + 16); group(p4.w, tl + g * 8 + 24);
+            }
+            if (G & 2) {
+                const unsigned long long p2 = *reinterpret_cast<const lds_u64*>(pr + g);
+                group((unsigned)p2, tl + g * 8); group((unsigned)(p2 >> 32), tl + g * 8 + 8);
+                g += 2;
+            }
+            if (G & 1) group(pr[g], tl + g * 8);
+            tl += (unsigned)(S * tp) * 8u;
+            pr += S * Gp;
+        }
+        if (t0 + lane < ntask) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -339,10 +440,18 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int rstep = strips ? 1 : L.step;                 // image rows from one unit row to the next
     const int upr = strips ? cols : nx;                    // units per row
     const int cpu = strips ? 4 : 1;                        // cells per unit
+    // Without a patch mask a cell's window energy is the sum of the squared image over the template's rectangle, whatever
+    // the template holds: the chunk-capable builds take it from box sums - every lane keeps the energy of two pixel
+    // columns over the th rows under the current cell row, slides it down row by row (and on from block to block), and
+    // a prefix sum over the lanes gives every cell's tw columns as a difference.  The numerators then need no entry
+    // lists either: every group counts with all four bytes, so a task walks template rows and groups in order, the
+    // P0 dwords of the whole template staying resident.
+    const int npix = L.aw + L.tw - 1;                       // pixel columns under the window
+    const bool box = CHUNKS && SEARCH && !has_mask && strips && npix <= 2 * SLAM_WG;
     int R = L.th, nchunk = 1;                              // template rows per chunk, chunks (lean_plan)
     int bh = rows_all, nblk = 1;                           // unit rows per block, blocks
     if (CHUNKS) {
-        const LeanPlan pl = lean_plan(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized, !SEARCH, lds_total);
+        const LeanPlan pl = lean_plan(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized, !SEARCH, lds_total, box);
         bh = uni_i32(pl.bh); R = uni_i32(pl.R);
         if (bh <= 0) { LEAN_REJECT(100); return out; }
         nblk = small_div_u(rows_all + bh - 1, bh);
@@ -353,7 +462,8 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const bool chunked = CHUNKS && nchunk > 1;
     const int NGc = R * G;                                 // groups the lists hold at most
     const int cap = lean_cap(NGc);                         // room for the padding entries and for reads a few entries ahead
-    const int list_bytes = cap * 8, marr_bytes = (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
+    // (box: no lists - the P0 dwords of the whole template take their place)
+    const int list_bytes = box ? (L.th * lean_pc_pitch(G) * 4 + 15) & ~15 : cap * 8, marr_bytes = box ? 0 : (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
     if (SEARCH && !CHUNKS) {
         // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
         if (L.tw > 256 || L.th > 256 || L.tw * L.th > 66051 || tp > 64) { LEAN_REJECT(101); return out; }
@@ -377,8 +487,10 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     lds_u64* list = reinterpret_cast<lds_u64*>(lds + acc_bytes);
     lds_u32* marr = reinterpret_cast<lds_u32*>(lds + acc_bytes + list_bytes);       // masks of list entries nA1, nA1 + 1, ...: the all-kept part has none
     lds_u8* tile = lds + acc_bytes + list_bytes + marr_bytes;
-    lds_u64* raw = reinterpret_cast<lds_u64*>(tile);       // {P0, M} per group in (row, group) order, until the tile is staged
-    lds_u64* taps = raw + NGc;
+    // {P0, M} per group in (row, group) order, until the tile is staged (box: of the whole template, from where the P0 dwords stay)
+    lds_u64* raw = box ? reinterpret_cast<lds_u64*>(list) : reinterpret_cast<lds_u64*>(tile);
+    lds_u64* taps = raw + (box ? NG : NGc);
+    lds_u32* pc = reinterpret_cast<lds_u32*>(list);        // box: P0 of every group of the template
 
     STAMP(50);
     // A template of at most 32 groups (the coarse levels of a walk) is not sorted into the two lists: compacting it
@@ -399,6 +511,8 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     int u0 = 0, Rc = L.th;                                  // the template rows the lists and the tile hold
     int lx = 0, ly = 0;
     float bv = 0.f;
+    unsigned box_e0 = 0, box_e1 = 0;                        // energies of pixel columns 2 * lane and 2 * lane + 1
+    int box_y = -2;                                         // the cell row they belong to
     // ---- blocks of cell rows, and within a block chunks of template rows: lists where they change, tile, sums; scores
     //      when a block's sums are complete; after the last block the argmax and, for the fit, the rows around it
     for (int blk = 0; blk <= nblk; blk++) {
@@ -428,10 +542,11 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
       int ch = 0;
       do {                                                  // (one pass unless the template is taken in chunks)
         if (chunked) { u0 = ch * R; Rc = min(R, L.th - u0); }
-      if ((blk == 0 && ch == 0) || chunked) {
+      if ((blk == 0 && ch == 0) || (chunked && !box)) {
         __syncthreads();                                   // the previous level's, block's or chunk's readers of this LDS are done
         // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
-        const int NGb = Rc * G;                            // groups of these template rows
+        const int ut = box ? 0 : u0, Rt = box ? L.th : Rc; // the template rows staged here
+        const int NGb = Rt * G;                            // groups of these template rows
         int nA = 0, nB = 0;
         if (!L.resized) {
         for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
@@ -439,7 +554,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             unsigned P0 = 0, M = 0;
             if (i < NGb) {
                 const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G;
-                const long long so = (long long)(u0 + u) * L.srcw + gq * 4;
+                const long long so = (long long)(ut + u) * L.srcw + gq * 4;
                 const unsigned P = load4(L.patch + so, L.limit);
                 const unsigned Mraw = has_mask ? load4(L.mask + so, L.limit) : 0x01010101u;
                 const int nb = min(4, L.tw - gq * 4);
@@ -456,17 +571,17 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     } else {
         // cv::resize of template and mask on the fly (feature.cpp:130-131): tap tables first, then one pixel per lane
         // and step - 4 source bytes of the patch, 4 of the mask, fixed-point blend - into the raw bytes
-        const int wpx = G * 4, ntap = wpx + Rc;
+        const int wpx = G * 4, ntap = wpx + Rt;
         for (int i = lane; i < ntap; i += SLAM_WG) {
             int so, c0, c1;
             if (i < wpx) resize_tap(min(i, L.tw - 1), L.scx, L.srcw, true, so, c0, c1);
-            else resize_tap(u0 + i - wpx, L.scy, L.srch, false, so, c0, c1);
+            else resize_tap(ut + i - wpx, L.scy, L.srch, false, so, c0, c1);
             taps[i] = ((unsigned long long)(((unsigned)c0 & 0xffffu) | ((unsigned)c1 << 16)) << 32) | (unsigned)so;
         }
         __syncthreads();
         lds_u8* rb = reinterpret_cast<lds_u8*>(raw);
         const float rw = __builtin_amdgcn_rcpf((float)wpx);
-        const int n = Rc * wpx;
+        const int n = Rt * wpx;
         for (int i0 = 0; i0 < n; i0 += SLAM_WG) {
             const int ii = i0 + lane;
             const bool live = ii < n;
@@ -497,8 +612,19 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             }
     }
     if (tiny) { nA = 0; nB = NG; }
-    if (!CHUNKS || (blk == 0 && ch == nchunk - 1)) nm = make_norms(wave_sum_u32(sp_part));       // |P0|^2 of the whole template
+    if (!CHUNKS || box || (blk == 0 && ch == nchunk - 1)) nm = make_norms(wave_sum_u32(sp_part));       // |P0|^2 of the whole template
     STAMP(51);
+    if (CHUNKS && box) {
+        // the P0 dwords move to the front of the staged pairs (a lane's write lands on bytes read in this pass or before)
+        __syncthreads();
+        const int Gp = lean_pc_pitch(G);
+        for (int i0 = 0; i0 < NG; i0 += SLAM_WG) {
+            const int i = i0 + lane;
+            const unsigned P0 = i < NG ? (unsigned)raw[i] : 0u;
+            __syncthreads();
+            if (i < NG) { const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G; pc[u * Gp + gq] = P0; }
+        }
+    } else {
 
     // ---- a handful of lattice cells under a small template (the coarse levels of a walk) --------------------------------
     // At most 32 cells and at most 16 template groups per lane: tile, lists and LDS accumulators would cost more than the sums themselves.
@@ -580,11 +706,43 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         }
         for (int p = nA + nB + lane; p < nA1 + nB1; p += SLAM_WG) { list[p] = 0ull; marr[p - nA1] = 0u; }   // padding: adds nothing
     }
+    }
     STAMP(52);
       }
         __syncthreads();                                    // lists complete; the previous block's readers of tile and sums done
         if (ch == 0)
             for (int i = lane; i < nunits * cpu * 2; i += SLAM_WG) acc[i] = 0;
+        if (CHUNKS && box && ch == 0) {
+            lds_u32* inc = reinterpret_cast<lds_u32*>(tile);    // inclusive prefix sums of the column energies (the tile is staged afterwards)
+            const bool in0 = 2 * lane < npix, in1 = 2 * lane + 1 < npix;
+            const uint8_t* c0 = L.im + (unsigned long long)(unsigned)L.y0 * L.ipitch + (unsigned)(L.x0 + min(2 * lane, npix - 1));
+            const uint8_t* c1 = L.im + (unsigned long long)(unsigned)L.y0 * L.ipitch + (unsigned)(L.x0 + min(2 * lane + 1, npix - 1));
+            for (int cy = 0; cy < rows_b; cy++) {
+                const int y = r0 + cy;
+                if (box_y == y - 1) {                       // one row down: the row above leaves, the row below enters
+                    const unsigned a0 = c0[(unsigned)(y - 1) * L.ipitch], a1 = c1[(unsigned)(y - 1) * L.ipitch];
+                    const unsigned b0 = c0[(unsigned)(y - 1 + L.th) * L.ipitch], b1 = c1[(unsigned)(y - 1 + L.th) * L.ipitch];
+                    box_e0 += b0 * b0 - a0 * a0; box_e1 += b1 * b1 - a1 * a1;
+                } else if (box_y != y) {                    // from scratch: the first block, or the rows around the peak
+                    box_e0 = 0; box_e1 = 0;
+                    for (int r = 0; r < L.th; r++) {
+                        const unsigned a0 = c0[(unsigned)(y + r) * L.ipitch], a1 = c1[(unsigned)(y + r) * L.ipitch];
+                        box_e0 += a0 * a0; box_e1 += a1 * a1;
+                    }
+                }
+                box_y = y;
+                const unsigned e0 = in0 ? box_e0 : 0u, e1 = in1 ? box_e1 : 0u;
+                const unsigned pre = wave_scan_u32(e0 + e1);
+                __syncthreads();                            // the previous row's readers of inc are done
+                inc[2 * lane] = pre - e1; inc[2 * lane + 1] = pre;
+                __syncthreads();
+                for (int x = lane; x < L.aw; x += SLAM_WG) {
+                    const unsigned hi = inc[x + L.tw - 1], lo = x > 0 ? inc[x - 1] : 0u;
+                    acc[2 * lean_strip_cell(x, cy, rows_b, nunits) + 1] = hi - lo;
+                }
+            }
+            __syncthreads();                                // inc is read before the tile overwrites it
+        }
         {   // image tile: byte windows W0 and W3 of every dword position, for the image rows under template rows u0 .. u0 + Rc - 1
             const int trows = (rows_b - 1) * rstep + Rc;
             const int lg = 32 - __builtin_clz((unsigned)tp);   // 2^lg > tp lanes per tile row
@@ -624,7 +782,8 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         }
         __syncthreads();
         STAMP(53);
-        if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, rows_b, tp, o, 1);
+        if (CHUNKS && box) lean_accumulate_rows(tile, pc + u0 * lean_pc_pitch(G), acc, nunits, lean_pick_row_slices(nunits, Rc, G), Rc, G, rows_b, tp);
+        else if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, rows_b, tp, o, 1);
         else lean_accumulate<1>(tile, list, marr, acc, nunits, S, na, nb, nA1, nx, tp, o, L.step);
         __syncthreads();
         STAMP(54);

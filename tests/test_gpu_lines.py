@@ -228,3 +228,55 @@ def test_line_track_random_shapes_against_oracle(ctx, oracle):
                 nbad += 1
                 print("trial", trial, subs, j["descriptor"].shape, j["area"], j["threshold"], j["stride"], g, r)
     assert nbad == 0
+
+
+@pytest.mark.parametrize("lds", [4096, 6400, 10240, 12800, 24576, 65536])
+def test_line_walks_do_not_depend_on_the_lean_coarse_search(oracle, lds, monkeypatch):
+    """Large batches search their coarsest level with the lean core first (line_lean_coarse_kernel: blocks of cell rows,
+    chunks of template rows, window energies from box sums of the squared image, numerators without entry lists);
+    forced here for small batches, at LDS budgets that move every block and chunk boundary.  Fixed cases (walks that end
+    on the coarsest level, areas over the border, constant descriptors) and random shapes - descriptors up to 150 pixels
+    wide, for which the box sums do not apply (more than 128 pixel columns under the window) and the entry lists are used."""
+    monkeypatch.setenv("SLAM_HIP_LINE_LEAN_MIN", "1")
+    monkeypatch.setenv("SLAM_HIP_LINE_BANDS", "1")
+    monkeypatch.setenv("SLAM_HIP_LINE_LEAN_LDS_BYTES", str(lds))
+    rng = np.random.default_rng(260 + lds + SOAK_SEED)
+    w, h = 640, 480
+    shift = (4, -3)
+    f0, f1 = synth.frame(w, h, 41 + SOAK_SEED), synth.frame(w, h, 41 + SOAK_SEED, shift)
+    nbad = 0
+    with api.Context(0) as c:
+        for subs, half, n in (([1.0, 2.0], 40, 10), ([2.0], 16, 6), ([1.0, 2.0, 4.0], 12, 8), ([1.0], 9, 6), ([1.0, 3.0], 33, 6)):
+            top = subs[-1]
+            jobs = _line_jobs(rng, w, h, subs, n, half, f0, shift)
+            for j in jobs:
+                j["area_mask"] = oracle.disc_mask(j["area"][2], j["area"][3], j["circles"])
+            jobs.append(dict(jobs[0], area=(-5, -7, 30, 25), area_mask=oracle.disc_mask(30, 25, [[12, 12, 11]])))      # over the corner
+            jobs.append(dict(jobs[1], threshold=1.5))                                       # ends on the coarsest level
+            jobs.append(dict(jobs[2], area=(jobs[2]["area"][0], jobs[2]["area"][1], 9, 2), area_mask=np.full((2, 9), 255, np.uint8)))
+            jobs.append(dict(jobs[3], descriptor=np.zeros_like(jobs[3]["descriptor"])))       # every score equal: the first cell wins
+            for k in range(16):                                                                # random shapes
+                dw, dh = int(rng.integers(1, 151)), int(rng.integers(1, 100))
+                cx, cy = int(rng.integers(dw // 2 + 2, w - dw)), int(rng.integers(dh // 2 + 2, h - dh))
+                d = f0[cy - dh // 2:cy - dh // 2 + dh, cx - dw // 2:cx - dw // 2 + dw].copy()
+                aw, ah = int(rng.integers(1, 100)), int(rng.integers(1, 70))
+                ax, ay = int(cx / top) - aw // 2 + int(rng.integers(-6, 7)), int(cy / top) - ah // 2 + int(rng.integers(-6, 7))
+                am = np.full((ah, aw), 255, np.uint8) if k % 2 else (rng.random((ah, aw)) < 0.5).astype(np.uint8) * 255
+                jobs.append(dict(frame=0, descriptor=d, area=(ax, ay, aw, ah), area_mask=am,
+                                 threshold=float(rng.choice([0.5, 0.9, 1.6])), stride=int(rng.integers(1, 4))))
+            pyr = api.ImagePyramid(c, f1, subs)
+            try:
+                got = api.line_track_batch(c, pyr, jobs)
+            finally:
+                pyr.close()
+            levels = oracle.pyramid(f1, subs)
+            for j, g in zip(jobs, got):
+                r = oracle.line_track(levels, subs, j["descriptor"], j["area"], j["area_mask"], j["threshold"], j["stride"])
+                same = g["status"] == 0 and (g["x"], g["y"], g["levels_run"]) == (r["x"], r["y"], r["levels_run"])
+                for key in ("response", "dx", "dy"):
+                    a, b = np.float32(g[key]), np.float32(r[key])
+                    same = same and ((np.isnan(a) and np.isnan(b)) or a.view(np.uint32) == b.view(np.uint32))
+                if not same:
+                    nbad += 1
+                    print(lds, subs, j["descriptor"].shape, j["area"], j["threshold"], j["stride"], g, r)
+    assert nbad == 0
