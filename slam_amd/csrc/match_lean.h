@@ -513,36 +513,10 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     float bv = 0.f;
     unsigned box_e0 = 0, box_e1 = 0;                        // energies of pixel columns 2 * lane and 2 * lane + 1
     int box_y = -2;                                         // the cell row they belong to
-    // ---- blocks of cell rows, and within a block chunks of template rows: lists where they change, tile, sums; scores
-    //      when a block's sums are complete; after the last block the argmax and, for the fit, the rows around it
-    for (int blk = 0; blk <= nblk; blk++) {
-        if (blk == nblk) {
-            // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The
-            // wave's maximum first, then the smallest cell index among the lanes that hold it (cv::minMaxLoc: first
-            // maximum in row-major order, NaN never wins).
-            const unsigned bkey = wave_max_u32(b.idx != INT_MAX ? __float_as_uint(b.v) + 1u : 0u);
-            const int bidx = (int)wave_min_u32((b.idx != INT_MAX && __float_as_uint(b.v) + 1u == bkey) ? (unsigned)b.idx : 0xFFFFFFFFu);
-            bv = __uint_as_float(bkey - 1u);
-            STAMP(55);
-            // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is
-            // a -1 of the untouched score map or there is none at all: the general kernel knows those cases.
-            if (bkey == 0u) { LEAN_REJECT(3); return out; }
-            lx = bidx & 0xffff; ly = bidx >> 16;
-            out.ok = true;
-            out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
-            out.response = bv;
-            if (!(refine_always || (double)bv < refine_below)) return out;
-            if (!strips) return out;                       // off the lattice the four neighbours are unvisited: no fit
-            if (nblk == 1) break;                          // the sums of the only block are still in place
-            r0 = max(ly - 1, 0); rows_b = min(ly + 1, L.ah - 1) - r0 + 1;
-        } else {
-            r0 = blk * bh; rows_b = min(bh, rows_all - r0);
-        }
-        const int nunits = rows_b * upr;
-      int ch = 0;
-      do {                                                  // (one pass unless the template is taken in chunks)
-        if (chunked) { u0 = ch * R; Rc = min(R, L.th - u0); }
-      if ((blk == 0 && ch == 0) || (chunked && !box)) {
+    // Template rows -> {P0, M} pairs -> entry lists (or, for a handful of lattice cells, the sums themselves).  The plain
+    // builds run this once, ahead of the blocks; the chunk-capable ones whenever the template rows change.
+    // Returns 0: lists in place; 1: every cell has been scored (the direct search); -1: not covered.
+    auto stage = [&](int blk, int ch, int nunits) -> int {
         __syncthreads();                                   // the previous level's, block's or chunk's readers of this LDS are done
         // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
         const int ut = box ? 0 : u0, Rt = box ? L.th : Rc; // the template rows staged here
@@ -638,7 +612,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     nb = lsl.nb;
     const int nB1 = nb * S;
     // a mask with more partly kept groups than a warped quadrilateral has (never true for single searches)
-    if (!SEARCH && !direct && nB1 + 2 > lean_mcap(NGc, R, true)) { LEAN_REJECT(4); return out; }
+    if (!SEARCH && !direct && nB1 + 2 > lean_mcap(NGc, R, true)) { LEAN_REJECT(4); return -1; }
     __syncthreads();                                        // raw is complete (direct path: written above by other lanes)
     if (direct) {
         const int ncell = nx * ny, pshift = dshift;
@@ -679,7 +653,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         }
         if (live && part == 0 && !(L.amask && L.amask[y * L.aw + x] == 0))
             best_update(b, score_f32_n(cc, si, nm.p2f), (y << 16) | x);
-        break;                                              // straight to the argmax
+        return 1;                                           // straight to the argmax
     } else if (tiny) {                                      // every group a masked entry, in template order
         if (lane < NG) {
             const unsigned long long r = raw[lane];
@@ -708,6 +682,47 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     }
     }
     STAMP(52);
+        return 0;
+    };
+    int blk0 = 0;
+    if (!CHUNKS) {
+        const int st = stage(0, 0, 0);
+        if (st < 0) return out;
+        if (st == 1) blk0 = nblk;
+    }
+    // ---- blocks of cell rows, and within a block chunks of template rows: lists where they change, tile, sums; scores
+    //      when a block's sums are complete; after the last block the argmax and, for the fit, the rows around it
+    for (int blk = blk0; blk <= nblk; blk++) {
+        if (blk == nblk) {
+            // Scores kept by best_update are >= 0 (never NaN): as unsigned integers their bits order like the values.  The
+            // wave's maximum first, then the smallest cell index among the lanes that hold it (cv::minMaxLoc: first
+            // maximum in row-major order, NaN never wins).
+            const unsigned bkey = wave_max_u32(b.idx != INT_MAX ? __float_as_uint(b.v) + 1u : 0u);
+            const int bidx = (int)wave_min_u32((b.idx != INT_MAX && __float_as_uint(b.v) + 1u == bkey) ? (unsigned)b.idx : 0xFFFFFFFFu);
+            bv = __uint_as_float(bkey - 1u);
+            STAMP(55);
+            // Visited cells score >= 0 or NaN.  If none scored (every visited cell NaN, or no cell visited), the maximum is
+            // a -1 of the untouched score map or there is none at all: the general kernel knows those cases.
+            if (bkey == 0u) { LEAN_REJECT(3); return out; }
+            lx = bidx & 0xffff; ly = bidx >> 16;
+            out.ok = true;
+            out.x = lx + L.x0 + L.tw / 2; out.y = ly + L.y0 + L.th / 2;      // + areaRect origin (matching.cpp:225-226)
+            out.response = bv;
+            if (!(refine_always || (double)bv < refine_below)) return out;
+            if (!strips) return out;                       // off the lattice the four neighbours are unvisited: no fit
+            if (nblk == 1) break;                          // the sums of the only block are still in place
+            r0 = max(ly - 1, 0); rows_b = min(ly + 1, L.ah - 1) - r0 + 1;
+        } else {
+            r0 = blk * bh; rows_b = min(bh, rows_all - r0);
+        }
+        const int nunits = rows_b * upr;
+      int ch = 0;
+      do {                                                  // (one pass unless the template is taken in chunks)
+        if (chunked) { u0 = ch * R; Rc = min(R, L.th - u0); }
+      if (CHUNKS && ((blk == 0 && ch == 0) || (chunked && !box))) {
+        const int st = stage(blk, ch, nunits);
+        if (st < 0) return out;
+        if (st == 1) break;
       }
         __syncthreads();                                    // lists complete; the previous block's readers of tile and sums done
         if (ch == 0)
