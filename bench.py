@@ -86,7 +86,7 @@ def parse_args(argv=None):
                     help="the extra legs to run, of fast,c1,c3,prod,line (profiling: the general walk kernel has work in the prod leg only)")
     ap.add_argument("--c3-walk-lds", type=int, default=10240, help="LDS bytes per walk of the lean kernel in the C3 leg")
     ap.add_argument("--c3-chunks", action="store_true", help="C3 leg through the lean kernel's build with template chunks")
-    ap.add_argument("--prod-walk-lds", type=int, default=15360,
+    ap.add_argument("--prod-walk-lds", type=int, default=10240,
                     help="LDS bytes per walk of the lean kernel's chunked build in the prod leg (0: general kernel only)")
     ap.add_argument("--no-fast-sparse", action="store_true",
                     help="FAST leg at threshold 10 only (profiling: keeps one kind of launch per kernel name)")
@@ -554,7 +554,8 @@ def c3_leg(api, capi, ctx, stream, dev, args, traffic):
     macs = float((ran * c3 * 2 * tw3 * tw3 + cum_m[np.maximum(lr - 1, 0)]).sum())
     ms = timed(stream, go, max(5, args.steps))
     ms_p = timed(stream, lambda: pyr.rebuild_d(d_fr.data_ptr(), w, w * h), max(5, args.steps))
-    out = search_report("track_lean_kernel@%d+track_kernel@4096" % len(jobs), "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
+    out = search_report("track_lean_kernel<%s>@%d+track_kernel@4096" % ("true" if args.c3_chunks else "false", len(jobs)),
+                        "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
                         {"workload": "C3: %dx%d, %d features/frame, %dx%d masked templates, pyramid {1,2,4,8}, ellipse windows "
                                      "(area masks) on the coarsest level, stride 3; %d frames" % (w, h, nfeat, ts, ts, nfr),
                          "jobs": len(jobs), "pyramid_ms": ms_p, "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
@@ -609,7 +610,7 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
     P = lambda t: C.c_void_p(t.data_ptr())
 
     # 81x81 descriptors do not fit the lean walk kernel's LDS whole: its build that takes the template in chunks of rows,
-    # with 12 granules of 1280 bytes per walk (10 walks per CU); 0 leaves every walk to the general kernel
+    # with 8 granules of 1280 bytes per walk (16 walks per CU); 0 leaves every walk to the general kernel
     if args.prod_walk_lds:
         capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, args.prod_walk_lds))
         capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 1))
@@ -650,8 +651,8 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
         capi.check(ctx.handle, L.slam_hip_track_batch_d(ctx.handle, pyr.handle, P(d_jobs), nfeat, P(d_blob), blob.size, P(d_res)))
     lat = timed(stream, one_frame, max(5, args.steps))
     go()
-    # (a profile key of its own: the general kernel runs with 4096 workgroups in every leg, and only here does it have work)
-    out = search_report("track_kernel@prod", "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
+    out = search_report("track_lean_kernel<%s>@%d+track_kernel@4096" % ("true" if args.prod_walk_lds else "false", len(jobs)),
+                        "track_lean_kernel+track_kernel", ms, positions, alg, macs, traffic,
                         {"workload": "the reference's live shape: %dx%d, %d features/frame, %dx%d masked descriptors, pyramid {1,3}, "
                                      "stride 3, threshold %.2f; %d frames" % (w, h, nfeat, ts, ts, THRESHOLD, nfr),
                          "jobs": len(jobs), "pyramid_ms": float(ms_p), "frames_per_s_with_pyramid": nfr / ((ms + ms_p) * 1e-3),
@@ -750,7 +751,7 @@ def line_leg(api, capi, ctx, stream, dev, args, traffic):
     lat1 = timed(stream, one_frame(ctx1), max(5, args.steps))
     ctx1.close()
     go()                                                          # d_res holds the whole batch again
-    out = search_report("line_track_kernel@%d" % len(jobs), "line_track_kernel", ms, float(c[lr].sum()), float(b[lr].sum()), float(m[lr].sum()), traffic,
+    out = search_report("line_lean_coarse_kernel@%d+line_track_kernel@%d" % (len(jobs), len(jobs)), "line_lean_coarse_kernel+line_track_kernel", ms, float(c[lr].sum()), float(b[lr].sum()), float(m[lr].sum()), traffic,
                         {"workload": "line walk: %dx%d, %d lines/frame, %dx%d descriptors, pyramid {1,2}, stride 2, %dx%d disc-union "
                                      "area on the coarsest level; %d frames" % (w, h, nline, ds, ds, aw, ah, nfr),
                          "jobs": len(jobs), "refined_at_full_resolution": float((lr == 2).mean()), "parity": parity,
@@ -1011,7 +1012,7 @@ def main(argv=None):
 
     if rank == 0:
         traffic = load_traffic()
-        tr = traffic_of(traffic, "track_lean_kernel@%d" % (8 * ((njobs + 7) // 8)), "track_kernel@%d" % min(njobs, 4096))
+        tr = traffic_of(traffic, "track_lean_kernel<false>@%d" % (8 * ((njobs + 7) // 8)), "track_kernel@%d" % min(njobs, 4096))
         ach = alg_bytes / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "NCC patch-match positions/sec (pyramid build + coarse-to-fine template search)",
@@ -1047,7 +1048,7 @@ def main(argv=None):
                          # the HBM fraction this workload would reach if nothing but its multiply-accumulates were issued
                          "hbm_frac_at_measured_dot_peak": alg_bytes / (macs / DOT4_PEAK_MEASURED) / 1e9 / HBM_PEAK_GBS,
                          "hbm_frac_at_nominal_dot_peak": alg_bytes / (macs / DOT4_PEAK_NOMINAL) / 1e9 / HBM_PEAK_GBS},
-            "lds": lds_report(kern_ms, "track_lean_kernel@%d" % (8 * ((njobs + 7) // 8)), "track_kernel@%d" % min(njobs, 4096)),
+            "lds": lds_report(kern_ms, "track_lean_kernel<false>@%d" % (8 * ((njobs + 7) // 8)), "track_kernel@%d" % min(njobs, 4096)),
             "cpu_baseline": cpu,
             "with_h2d": with_h2d,
             # the other kernels and configurations BASELINE.json names, measured in the same run (outside the timed steps)

@@ -10,11 +10,8 @@ TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-# the general walk kernel (track_kernel, 4096 workgroups in every leg) has work in the prod leg only: that leg is profiled
-# in passes of its own (prod_*), where its launches are told from the empty ones by their counter values
-BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu --no-fast-sparse --legs fast,c1,c3,line"
-BENCH_PMC="python3 $PWD/bench.py --steps 3 --warmup 1 --repeats 2 --no-cpu --no-fast-sparse --legs fast,c1,c3,line"
-BENCH_PROD="python3 $PWD/bench.py --steps 3 --warmup 1 --repeats 2 --no-cpu --legs prod"
+BENCH="python3 $PWD/bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu --no-fast-sparse"
+BENCH_PMC="python3 $PWD/bench.py --steps 3 --warmup 1 --repeats 2 --no-cpu --no-fast-sparse"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 echo "stats pass done"
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $BENCH_PMC > $OUT/fetch.log 2>&1
@@ -23,11 +20,6 @@ timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- $BENCH_
 echo "write pass done"
 timeout -s KILL 240 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/lds -o lds -- $BENCH_PMC > $OUT/lds.log 2>&1
 echo "lds pass done"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/prod_stats -o stats -- $BENCH_PROD > $OUT/prod_stats.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/prod_fetch -o fetch -- $BENCH_PROD > $OUT/prod_fetch.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/prod_write -o write -- $BENCH_PROD > $OUT/prod_write.log 2>&1
-timeout -s KILL 240 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE -d $OUT/prod_lds -o lds -- $BENCH_PROD > $OUT/prod_lds.log 2>&1
-echo "prod passes done"
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/calib_fetch -o calib -- $PWD/profiles/tools/pmc_calib.bin > $OUT/calib_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $OUT/calib_write -o calib -- $PWD/profiles/tools/pmc_calib.bin > $OUT/calib_write.log 2>&1
 echo "calibration passes done"

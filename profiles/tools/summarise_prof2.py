@@ -43,28 +43,13 @@ def counter_by_kernel(path, counter):
     return {"%s@%d" % (short(n), wg): (c, v) for n, wg, c, v in rows if not short(n).startswith("at::") and "rocclr" not in n}
 
 
-def heavy_launches(path, counter, kernel_sub, wg):
-    """Mean of one counter over the launches of a kernel (name contains kernel_sub, wg workgroups) that did work: those
-    whose value is above half the largest (the prod passes: the same kernel also runs with an empty queue)."""
-    if not os.path.exists(path):
-        return None
-    db = sqlite3.connect(path)
-    vals = [v for (v,) in db.execute("select value from counters_collection where counter_name=? and kernel_name like ? and grid_size / workgroup_size = ?",
-                                      (counter, "%" + kernel_sub + "%", wg))]
-    if not vals:
-        return None
-    top = max(vals)
-    sel = [v for v in vals if v > 0.5 * top]
-    return sum(sel) / len(sel), len(sel)
-
-
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     nseq = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     prof = os.path.join(ROOT, "profiles")
     text, avg = kernel_stats(sqlite3.connect(os.path.join(src, "stats", "stats_results.db")))
     with open(os.path.join(prof, tag + "_kernel_stats.txt"), "w") as fh:
-        fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu --no-fast-sparse   (1 GPU, %d sequences per step)\n" % nseq)
+        fh.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --repeats 5 --no-cpu --no-fast-sparse   (1 GPU, %d sequences per step)\n" % nseq)
         fh.write(text + "\n")
     print(text)
     fetch = counter_by_kernel(os.path.join(src, "fetch", "fetch_results.db"), "FETCH_SIZE")
@@ -116,20 +101,6 @@ def main():
         hbm = f[1] * 1024.0 * corr + w[1] * 1024.0
         out["kernels"][k] = {"fetch_size_kb": f[1], "write_size_kb": w[1], "read_correction": corr, "hbm_bytes_per_launch": hbm}
         lines.append("%-58s %8d %14.1f %14.1f %16.0f" % (k[:58], f[0], f[1], w[1], hbm))
-    # the reference's live shape (prod leg): the general walk kernel's launches that had work
-    pf = heavy_launches(os.path.join(src, "prod_fetch", "fetch_results.db"), "FETCH_SIZE", "track_kernel", 4096)
-    pw = heavy_launches(os.path.join(src, "prod_write", "write_results.db"), "WRITE_SIZE", "track_kernel", 4096)
-    if pf and pw:
-        hbm = pf[0] * 1024.0 * corr + pw[0] * 1024.0
-        out["kernels"]["track_kernel@prod"] = {"fetch_size_kb": pf[0], "write_size_kb": pw[0], "read_correction": corr, "hbm_bytes_per_launch": hbm}
-        lines.append("%-58s %8d %14.1f %14.1f %16.0f" % ("track_kernel@4096 (prod leg, launches with work)", pf[1], pf[0], pw[0], hbm))
-    pa = heavy_launches(os.path.join(src, "prod_lds", "lds_results.db"), "SQ_LDS_IDX_ACTIVE", "track_kernel", 4096)
-    pc = heavy_launches(os.path.join(src, "prod_lds", "lds_results.db"), "SQ_LDS_BANK_CONFLICT", "track_kernel", 4096)
-    pg = heavy_launches(os.path.join(src, "prod_lds", "lds_results.db"), "GRBM_GUI_ACTIVE", "track_kernel", 4096)
-    if pa and pc and pg:
-        g = pg[0] / 8.0
-        out["lds"]["track_kernel@prod"] = {"array_cycles": pa[0], "conflict_cycles": pc[0], "cycles_per_xcd": g, "array_busy": pa[0] / (g * 256.0),
-                                           "bytes_upper_bound": (pa[0] - pc[0]) * 256.0}
     with open(os.path.join(prof, tag + "_pmc_traffic.txt"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     print("\n".join(lines))

@@ -244,22 +244,9 @@ __device__ __forceinline__ float lean_score(const lds_u32* acc, int ai, const No
 
 // One entry of the lists for the NC cells of a unit: cc += <window, P0>, si += <window & M, window & M>.  A tile entry
 // holds the byte windows W0 (bytes 0..3 from its position) and W3 (bytes 3..6); W1 and W2 are picked out of the two.
-template <int NC, bool MASKED, bool SI = true>
+template <int NC, bool MASKED>
 __device__ __forceinline__ void lean_step(const lds_u8* wp, unsigned P0, unsigned M, unsigned sel, unsigned (&cc)[NC], unsigned (&si)[NC]) {
-    if (!SI) {
-        // numerators only: the window energies come from box sums of the squared image (lean_level)
-        const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
-        const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
-        if (NC == 4) {
-            const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
-            cc[0] = __builtin_amdgcn_udot4(w0, P0, cc[0], false);
-            cc[1 % NC] = __builtin_amdgcn_udot4(w1, P0, cc[1 % NC], false);
-            cc[2 % NC] = __builtin_amdgcn_udot4(w2, P0, cc[2 % NC], false);
-            cc[3 % NC] = __builtin_amdgcn_udot4(w3, P0, cc[3 % NC], false);
-        } else {
-            cc[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_perm(w3, w0, sel), P0, cc[0], false);
-        }
-    } else if (NC == 4) {
+    if (NC == 4) {
         const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
         const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
         const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
@@ -290,7 +277,7 @@ __device__ __forceinline__ unsigned lean_window_sel(unsigned k) {
 // slice, so an entry read is one broadcast address and the window reads of a lane group fall on 16-byte tile entries an
 // odd number of entries apart (distinct banks).  Entries are fetched four ahead of their use; the lists are padded so that reading
 // up to four entries past a slice stays inside them.
-template <int NC, bool SI = true>
+template <int NC>
 __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u64* list, const lds_u32* marr, lds_u32* acc,
                                                 int nunits, int S, int na, int nb, int nA1, int div_units, int tp, int o, int step) {
     const int lane = lane_here();
@@ -316,14 +303,14 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
             for (; e + 4 <= na; e += 4) {
                 const unsigned long long c0 = q0, c1 = q1, c2 = q2, c3 = q3;
                 q0 = ea[e + 4]; q1 = ea[e + 5]; q2 = ea[e + 6]; q3 = ea[e + 7];
-                lean_step<NC, false, SI>(tl + (unsigned)(c0 >> 32), (unsigned)c0, 0u, sel, cc, si);
-                lean_step<NC, false, SI>(tl + (unsigned)(c1 >> 32), (unsigned)c1, 0u, sel, cc, si);
-                lean_step<NC, false, SI>(tl + (unsigned)(c2 >> 32), (unsigned)c2, 0u, sel, cc, si);
-                lean_step<NC, false, SI>(tl + (unsigned)(c3 >> 32), (unsigned)c3, 0u, sel, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c0 >> 32), (unsigned)c0, 0u, sel, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c1 >> 32), (unsigned)c1, 0u, sel, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c2 >> 32), (unsigned)c2, 0u, sel, cc, si);
+                lean_step<NC, false>(tl + (unsigned)(c3 >> 32), (unsigned)c3, 0u, sel, cc, si);
             }
-            if (e < na) lean_step<NC, false, SI>(tl + (unsigned)(q0 >> 32), (unsigned)q0, 0u, sel, cc, si);
-            if (e + 1 < na) lean_step<NC, false, SI>(tl + (unsigned)(q1 >> 32), (unsigned)q1, 0u, sel, cc, si);
-            if (e + 2 < na) lean_step<NC, false, SI>(tl + (unsigned)(q2 >> 32), (unsigned)q2, 0u, sel, cc, si);
+            if (e < na) lean_step<NC, false>(tl + (unsigned)(q0 >> 32), (unsigned)q0, 0u, sel, cc, si);
+            if (e + 1 < na) lean_step<NC, false>(tl + (unsigned)(q1 >> 32), (unsigned)q1, 0u, sel, cc, si);
+            if (e + 2 < na) lean_step<NC, false>(tl + (unsigned)(q2 >> 32), (unsigned)q2, 0u, sel, cc, si);
         }
         {   // partly masked groups (and the padding entries, mask 0)
             const lds_u64* eb = list + nA1 + slice * nb;
@@ -335,16 +322,16 @@ __device__ __forceinline__ void lean_accumulate(const lds_u8* tile, const lds_u6
                 const unsigned long long c0 = q0, c1 = q1;
                 const unsigned k0 = m0, k1 = m1;
                 q0 = eb[e + 2]; q1 = eb[e + 3]; m0 = mb[e + 2]; m1 = mb[e + 3];
-                lean_step<NC, SI, SI>(tl + (unsigned)(c0 >> 32), (unsigned)c0, k0, sel, cc, si);
-                lean_step<NC, SI, SI>(tl + (unsigned)(c1 >> 32), (unsigned)c1, k1, sel, cc, si);
+                lean_step<NC, true>(tl + (unsigned)(c0 >> 32), (unsigned)c0, k0, sel, cc, si);
+                lean_step<NC, true>(tl + (unsigned)(c1 >> 32), (unsigned)c1, k1, sel, cc, si);
             }
-            if (e < nb) lean_step<NC, SI, SI>(tl + (unsigned)(q0 >> 32), (unsigned)q0, m0, sel, cc, si);
+            if (e < nb) lean_step<NC, true>(tl + (unsigned)(q0 >> 32), (unsigned)q0, m0, sel, cc, si);
         }
         if (t0 + lane < ntask) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2, cc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (SI) __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2 + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2 + 1, si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
