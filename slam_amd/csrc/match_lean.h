@@ -594,7 +594,10 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     // sums of a cell meet by DPP butterflies, and the cell's first lane scores it.  Same integer sums, same formula, same
     // argmax rule as below.  (The last group's dword may reach up to 3 bytes past the template: it must stay inside
     // the image row.  Off the lattice there is no sub-pixel fit - the neighbours are unvisited - so none is needed here.)
-    const LeanSlices lsl = direct ? LeanSlices{1, 0, 0} : lean_pick_slices(chunked ? nunits : bh * upr, nA, nB, strips);
+    LeanSlices lsl = direct ? LeanSlices{1, 0, 0} : lean_pick_slices(chunked ? nunits : bh * upr, nA, nB, strips);
+    // (the chunk-capable builds pick slices per chunk and block: where the padding of the masked part to a multiple of
+    //  the slice count is what overflows the mask array, one slice - no padding - still fits)
+    if (CHUNKS && !SEARCH && !direct && lsl.nb * lsl.S + 2 > lean_mcap(NGc, R, true)) lsl = LeanSlices{1, nA, nB};
     S = lsl.S; na = lsl.na; nA1 = na * S;                   // all-kept entries per slice; the rest of them joins the masked part
     nb = lsl.nb;
     const int nB1 = nb * S;
@@ -708,7 +711,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         if (chunked) { u0 = ch * R; Rc = min(R, L.th - u0); }
       if (CHUNKS && ((blk == 0 && ch == 0) || (chunked && !box))) {
         const int st = stage(blk, ch, nunits);
-        if (st < 0) return out;
+        if (st < 0) { out.ok = false; return out; }        // (also from the rows around the peak: the position found so far is dropped with it)
         if (st == 1) break;
       }
         __syncthreads();                                    // lists complete; the previous block's readers of tile and sums done

@@ -82,6 +82,35 @@ def test_chunked_walks_equal_the_oracle_at_every_budget(oracle, lds, subs):
         assert left == 0, left                         # every walk is interior: none is left to the general kernel
 
 
+@pytest.mark.parametrize("lds", [4096, 4608, 5248, 6016, 7040])
+def test_fit_around_the_peak_of_a_search_in_blocks_and_chunks(oracle, lds):
+    """Wide windows (stride 4 under pyramid {1, 3}: 32x32 cells at full resolution) under narrow, tall templates at small
+    budgets: several blocks of cell rows and several chunks of template rows, and the sub-pixel fit of the last level
+    re-sums the rows around the peak chunk by chunk, with slices picked anew for those few rows."""
+    rng = np.random.default_rng(lds + 9 + SOAK_SEED)
+    w, h, subs, shift = 480, 400, [1.0, 3.0], (2, -1)
+    f0, f1 = synth.frame(w, h, 77), synth.frame(w, h, 77, shift)
+    jobs = _interior_jobs(rng, f0, shift, [(19, 33), (17, 29), (23, 41), (9, 57)], 5, 60)
+    for j in jobs:
+        j["stride"] = 4
+    with api.Context(0) as c:
+        L = api.capi.lib()
+        api.capi.check(c.handle, L.slam_hip_set_walk_lds(c.handle, lds))
+        api.capi.check(c.handle, L.slam_hip_set_walk_chunks(c.handle, 1))
+        pyr = api.ImagePyramid(c, f1, subs)
+        try:
+            got = api.track_batch(c, pyr, jobs)
+        finally:
+            pyr.close()
+    levels = oracle.pyramid(f1, subs)
+    bad = []
+    for k, (j, g) in enumerate(zip(jobs, got)):
+        r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+        if not _same(g, r):
+            bad.append((k, j["proj"].shape, g, r))
+    assert not bad, bad[:4]
+
+
 def test_the_plain_build_leaves_large_templates_to_the_general_kernel_and_the_chunked_one_takes_them(oracle):
     rng = np.random.default_rng(5 + SOAK_SEED)
     w, h, subs, shift = 640, 480, [1.0, 3.0], (-2, 5)
