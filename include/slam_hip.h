@@ -367,7 +367,9 @@ typedef struct slam_line_job {
 /* A batch of fewer than 1536 lines (the reference tracks three per frame, new_image.cpp:80) has each line's coarsest
  * search cut into up to 8 bands of rows, one wavefront each (one launch more; same results); the band results live in
  * a buffer of the context that grows when a batch needs more than any before it - the only allocation this entry point
- * can make. */
+ * can make.  A batch of 1024 lines or more has its coarsest searches done by a leaner kernel first (window energies
+ * from box sums of the squared image, lineFeature.cpp:124-127 searches without a patch mask), with the same record per
+ * line in the same buffer; same results. */
 int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const slam_line_job* d_jobs,
                                 int njobs, const uint8_t* d_blob, size_t blob_bytes,
                                 slam_track_result* d_out);
