@@ -86,7 +86,7 @@ def parse_args(argv=None):
                     help="the extra legs to run, of fast,c1,c3,prod,line (profiling: the general walk kernel has work in the prod leg only)")
     ap.add_argument("--c3-walk-lds", type=int, default=10240, help="LDS bytes per walk of the lean kernel in the C3 leg")
     ap.add_argument("--c3-chunks", action="store_true", help="C3 leg through the lean kernel's build with template chunks")
-    ap.add_argument("--prod-walk-lds", type=int, default=10240,
+    ap.add_argument("--prod-walk-lds", type=int, default=12800,
                     help="LDS bytes per walk of the lean kernel's chunked build in the prod leg (0: general kernel only)")
     ap.add_argument("--no-fast-sparse", action="store_true",
                     help="FAST leg at threshold 10 only (profiling: keeps one kind of launch per kernel name)")
@@ -610,7 +610,7 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
     P = lambda t: C.c_void_p(t.data_ptr())
 
     # 81x81 descriptors do not fit the lean walk kernel's LDS whole: its build that takes the template in chunks of rows,
-    # with 8 granules of 1280 bytes per walk (16 walks per CU); 0 leaves every walk to the general kernel
+    # with 10 granules of 1280 bytes per walk (12 walks per CU); 0 leaves every walk to the general kernel
     if args.prod_walk_lds:
         capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, args.prod_walk_lds))
         capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 1))

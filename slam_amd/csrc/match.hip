@@ -18,6 +18,9 @@ using namespace slamdev;
 #ifndef SLAM_MIN_WAVES
 #define SLAM_MIN_WAVES 4
 #endif
+#ifndef SLAM_MIN_WAVES_CHUNKS
+#define SLAM_MIN_WAVES_CHUNKS 4       // the lean walk kernel's build with blocks and chunks (track_lean_kernel<true>)
+#endif
 #ifndef SLAM_MIN_WAVES_LINE
 #define SLAM_MIN_WAVES_LINE 3
 #endif
@@ -537,7 +540,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
             const int step = q == 0 ? 1 : job.stride;
             const int nx = step == 1 ? aw : small_div(aw + step - 1, step), ny = step == 1 ? ah : small_div(ah + step - 1, step);
             fits = aw >= 1 && ah >= 1 && aw <= 255 && ah <= 255 &&
-                   (CHUNKS ? lean_plan(lvl_t, oth, aw, ah, step, nx, ny, sub != 1.f, true, lds_total).bh > 0
+                   (CHUNKS ? lean_plan(lvl_t, oth, aw, ah, step, nx, ny, sub != 1.f, true, lds_total, lean_box_mode(false, true, step, sub != 1.f, lvl_t, oth, aw)).bh > 0
                            : lean_need(lvl_t, oth, aw, ah, step, nx, ny, sub != 1.f) <= lds_total);
         }
         if (__ballot(!fits) != 0ull) { LEAN_REJECT(13); return false; }
@@ -597,7 +600,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
 }
 
 template <bool CHUNKS>
-__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_lean_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+__global__ __launch_bounds__(SLAM_WG, CHUNKS ? SLAM_MIN_WAVES_CHUNKS : SLAM_MIN_WAVES) void track_lean_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
                                                         int njobs, const uint8_t* __restrict__ blob,
                                                         unsigned long long blob_bytes,
                                                         slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
@@ -1063,7 +1066,7 @@ extern "C" int slam_hip_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, const 
 // kernel's LDS to the largest need among the walks it could take (the host-side replica of lean_walk's fit check;
 // sizing only - the device decides), within [default, 24 KB], for that launch alone.  Walks with a level beyond 24 KB
 // that the kernel's other build can take in blocks of cell rows and chunks of template rows (lean_plan) select that
-// build, with the smallest budget in whole granules at which every chunk has SLAM_AUTO_CHUNK_ROWS rows or more.  A
+// build, with the first budget of a short list at which every chunk has SLAM_AUTO_CHUNK_ROWS rows or more.  A
 // budget or build set by the caller (slam_hip_set_walk_lds, slam_hip_set_walk_chunks, SLAM_HIP_WALK_LDS_KB) is left alone.
 #define SLAM_AUTO_CHUNK_ROWS 10
 void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* jobs, int njobs) {
@@ -1097,12 +1100,16 @@ void slam_size_walk_lds(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job
         }
         if (worst == INT_MAX) continue;                    // a shape the lean kernels do not take at any budget
         if (worst <= 24576) { need = std::max(need, worst); continue; }
-        if (need_chunked >= 24320) continue;
-        for (int b = std::max(need_chunked, ctx->lean_lds_bytes / 1280 * 1280); b <= 24320; b += 1280) {
+        // budgets in the order of preference measured on the reference's live shape (81x81 descriptors, 24x24 windows):
+        // 10 granules (12 walks per CU) before 12 and 8
+        static const int order[] = {12800, 15360, 10240, 17920, 20480, 24320};
+        for (int b : order) {
+            if (b < need_chunked || b < ctx->lean_lds_bytes) continue;
             bool all = true;
             for (int q = 0; q < nlev && all; q++) {
                 const Shape& h = sh[q];
-                const LeanPlan pl = lean_plan(h.tw, h.th, h.aw, h.ah, h.step, h.nx, h.ny, h.resized, true, b);
+                const LeanPlan pl = lean_plan(h.tw, h.th, h.aw, h.ah, h.step, h.nx, h.ny, h.resized, true, b,
+                                              lean_box_mode(false, true, h.step, h.resized, h.tw, h.th, h.aw));
                 all = pl.bh > 0 && pl.R >= std::min(SLAM_AUTO_CHUNK_ROWS, h.th);
             }
             if (all) { need_chunked = std::max(need_chunked, b); break; }

@@ -175,13 +175,29 @@ __host__ __device__ __forceinline__ int lean_div(int n, int d) {
 #endif
 }
 
+// Which searches of the chunk-capable builds take their window energies from box sums of the squared image (see
+// lean_level): 0 none; 1 templates without a mask (single searches: the P0 dwords of the whole template stay resident);
+// 2 masked templates of walks, stored at this level's resolution and large enough for the box sums to pay (their cost
+// grows with the cell rows, the cost of the dots they replace with strips x template groups).
+#define LEAN_BOX_NONE 0
+#define LEAN_BOX_UNMASKED 1
+#define LEAN_BOX_MASKED 2
+__host__ __device__ __forceinline__ int lean_box_mode(bool search, bool has_mask, int step, bool resized, int tw, int th, int aw) {
+    if (step != 1 || aw + tw - 1 > 2 * SLAM_WG) return LEAN_BOX_NONE;
+    if (!has_mask) return search ? LEAN_BOX_UNMASKED : LEAN_BOX_NONE;
+    const int G = (tw + 3) >> 2, cols = (aw + 3) >> 2;
+    return !search && !resized && th * G * cols >= 2048 ? LEAN_BOX_MASKED : LEAN_BOX_NONE;
+}
+
 __host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, int cpu, int rstep, int rows_all, int bh, int R, bool resized, bool walk,
-                                                        int th, bool box) {
+                                                        int th, int box) {
     const int NGc = R * G;
     const int fit_rows = rows_all < 3 ? rows_all : 3;      // the three rows around the peak are summed at once for the fit
     const int acc = ((bh > fit_rows ? bh : fit_rows) * upr * cpu * 8 + 15) & ~15;
     int tile = (((bh - 1) * rstep + R) * tp * 8 + 15) & ~15;
     if (tile < 2 * SLAM_WG * 4) tile = 2 * SLAM_WG * 4;    // the box sums' prefix array lives there before the tile
+    if (box == LEAN_BOX_MASKED)                            // the chunk's P0 dwords, its complement list (every group at worst), the tile
+        return acc + ((R * lean_pc_pitch(G) * 4 + 15) & ~15) + (NGc + LEAN_MAX_S + 4) * 8 + tile;
     if (box) {
         // no lists: the whole template's P0 dwords stay resident, staged (8 bytes a group, taps behind them) where the
         // tile goes afterwards
@@ -194,7 +210,7 @@ __host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, 
 }
 
 __host__ __device__ __forceinline__ LeanPlan lean_plan(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized, bool walk, int budget,
-                                                       bool box = false) {
+                                                       int box = LEAN_BOX_NONE) {
     LeanPlan best = {0, 0};
     const int G = (tw + 3) >> 2;
     const bool strips = step == 1;
@@ -212,7 +228,8 @@ __host__ __device__ __forceinline__ LeanPlan lean_plan(int tw, int th, int aw, i
         int R = th;
         if (lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, th, resized, walk, th, box) > budget) {
             const int room = budget - lean_plan_bytes(G, tp, upr, cpu, rstep, rows_all, bh, 0, resized, walk, th, box);
-            const int per_row = box ? tp * 8 : G * 8 + (walk ? 12 : G * 4) + tp * 8;      // list entries, mask entries, a tile row
+            const int per_row = box == LEAN_BOX_MASKED ? lean_pc_pitch(G) * 4 + G * 8 + tp * 8 : box ? tp * 8
+                                : G * 8 + (walk ? 12 : G * 4) + tp * 8;           // list entries, mask entries, a tile row
             if (room < per_row * LEAN_MIN_CHUNK) continue;
             R = lean_div(room, per_row);
             if (R > th - 1) R = th - 1;
@@ -223,7 +240,7 @@ __host__ __device__ __forceinline__ LeanPlan lean_plan(int tw, int th, int aw, i
         }
         const int nch = R == th ? 1 : lean_div(th + R - 1, R);
         const int nbl = lean_div(rows_all + bh - 1, bh);
-        const int cost = nbl * nch * (((bh - 1) * rstep + R) * tp + (box ? 0 : R * G * (resized ? 16 : 2)) + 64);
+        const int cost = nbl * nch * (((bh - 1) * rstep + R) * tp + (box == LEAN_BOX_UNMASKED ? 0 : R * G * (resized ? 16 : 2)) + 64);
         if (cost < best_cost) { best_cost = cost; best.bh = bh; best.R = R; }
         if (nb == 1 && R == th) break;                     // everything at once
     }
@@ -399,6 +416,55 @@ __device__ __forceinline__ void lean_accumulate_rows(const lds_u8* tile, const l
     }
 }
 
+// What the box sums count too much under a masked template: for every group that drops pixels, the energy of the dropped
+// ones - si -= <window & C, window & C> with C the group's complement mask inside the template - over a list of
+// {C, tile offset} entries padded with null entries to S slices of equal length (tasks as in lean_accumulate).
+__device__ __forceinline__ void lean_accumulate_dropped(const lds_u8* tile, const lds_u64* clist, lds_u32* acc, int nunits, int nc, int rows, int tp) {
+    if (nc == 0) return;
+    const int lane = lane_here();
+    int S = 1, per = nc, best_c = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        constexpr int cand[6] = {1, 2, 3, 4, 6, 8};        // at most LEAN_MAX_S
+        const int s = cand[q];
+        const int n = (nc + s - 1) / s;
+        const int c = ((nunits * s + SLAM_WG - 1) >> 6) * (n * 12 + 20);
+        if (c < best_c) { best_c = c; S = s; per = n; }
+    }
+    const int ntask = nunits * S;
+    const float rnu = __builtin_amdgcn_rcpf((float)nunits), rdu = __builtin_amdgcn_rcpf((float)rows);
+    for (int t0 = 0; t0 < ntask; t0 += SLAM_WG) {
+        const int task = min(t0 + lane, ntask - 1);        // surplus lanes repeat the last task and do not flush
+        const int slice = (int)(((float)task + 0.5f) * rnu), unit = task - slice * nunits;
+        const int uq = (int)(((float)unit + 0.5f) * rdu), um = unit - uq * rows;
+        const lds_u8* tl = tile + (unsigned)(um * tp + uq) * 8u;
+        const lds_u64* e = clist + slice * per;
+        unsigned si[4] = {0u, 0u, 0u, 0u};
+        unsigned long long q0 = e[0], q1 = e[1];
+        for (int j = 0; j < per; j += 2) {
+            const unsigned long long c0 = q0, c1 = q1;
+            q0 = e[j + 2]; q1 = e[j + 3];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned long long c = h ? c1 : c0;
+                if (h && j + 1 >= per) break;
+                const unsigned cm = (unsigned)c;
+                const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(tl + (unsigned)(c >> 32));
+                const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
+                const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
+                const unsigned m0 = w0 & cm, m1 = w1 & cm, m2 = w2 & cm, m3 = w3 & cm;
+                si[0] = __builtin_amdgcn_udot4(m0, m0, si[0], false); si[1] = __builtin_amdgcn_udot4(m1, m1, si[1], false);
+                si[2] = __builtin_amdgcn_udot4(m2, m2, si[2], false); si[3] = __builtin_amdgcn_udot4(m3, m3, si[3], false);
+            }
+        }
+        if (t0 + lane < ntask) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2 + 1, 0u - si[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 // One search.  SEARCH = false: a level of a point walk - a patch mask is present, scores by the F32 formula, and the caller
 // has checked (lean_need) that the whole window fits the LDS at once.  SEARCH = true: a single matchFeatureInArea call -
 // the patch mask may be absent, the formula is L.mt's, and a window whose sums do not fit the LDS at once is searched
@@ -434,11 +500,15 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     // lists either: every group counts with all four bytes, so a task walks template rows and groups in order, the
     // P0 dwords of the whole template staying resident.
     const int npix = L.aw + L.tw - 1;                       // pixel columns under the window
-    const bool box = CHUNKS && SEARCH && !has_mask && strips && npix <= 2 * SLAM_WG;
+    // Under a masked template (walks, from a size on where it pays: lean_box_mode) the box sums count the dropped pixels
+    // too: their energy is taken off again by dots over the groups that drop any (lean_accumulate_dropped), a short list
+    // for the masks of warped quadrilaterals; the numerators run in row order as well, over the P0 = patch & mask dwords.
+    const int boxmode = CHUNKS ? lean_box_mode(SEARCH, has_mask, L.step, L.resized, L.tw, L.th, L.aw) : LEAN_BOX_NONE;
+    const bool box = boxmode != LEAN_BOX_NONE, boxm = boxmode == LEAN_BOX_MASKED;
     int R = L.th, nchunk = 1;                              // template rows per chunk, chunks (lean_plan)
     int bh = rows_all, nblk = 1;                           // unit rows per block, blocks
     if (CHUNKS) {
-        const LeanPlan pl = lean_plan(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized, !SEARCH, lds_total, box);
+        const LeanPlan pl = lean_plan(L.tw, L.th, L.aw, L.ah, L.step, nx, ny, L.resized, !SEARCH, lds_total, boxmode);
         bh = uni_i32(pl.bh); R = uni_i32(pl.R);
         if (bh <= 0) { LEAN_REJECT(100); return out; }
         nblk = small_div_u(rows_all + bh - 1, bh);
@@ -449,8 +519,9 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const bool chunked = CHUNKS && nchunk > 1;
     const int NGc = R * G;                                 // groups the lists hold at most
     const int cap = lean_cap(NGc);                         // room for the padding entries and for reads a few entries ahead
-    // (box: no lists - the P0 dwords of the whole template take their place)
-    const int list_bytes = box ? (L.th * lean_pc_pitch(G) * 4 + 15) & ~15 : cap * 8, marr_bytes = box ? 0 : (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
+    // (box: no lists - the P0 dwords of the whole template, or of a chunk and its list of groups that drop pixels, take their place)
+    const int list_bytes = boxm ? (R * lean_pc_pitch(G) * 4 + 15) & ~15 : box ? (L.th * lean_pc_pitch(G) * 4 + 15) & ~15 : cap * 8;
+    const int marr_bytes = boxm ? (NGc + LEAN_MAX_S + 4) * 8 : box ? 0 : (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
     if (SEARCH && !CHUNKS) {
         // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
         if (L.tw > 256 || L.th > 256 || L.tw * L.th > 66051 || tp > 64) { LEAN_REJECT(101); return out; }
@@ -477,15 +548,18 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     // {P0, M} per group in (row, group) order, until the tile is staged (box: of the whole template, from where the P0 dwords stay)
     lds_u64* raw = box ? reinterpret_cast<lds_u64*>(list) : reinterpret_cast<lds_u64*>(tile);
     lds_u64* taps = raw + (box ? NG : NGc);
-    lds_u32* pc = reinterpret_cast<lds_u32*>(list);        // box: P0 of every group of the template
+    lds_u32* pc = reinterpret_cast<lds_u32*>(list);        // box: P0 of every group of the template (masked: of the chunk)
+    lds_u64* clist = reinterpret_cast<lds_u64*>(marr);     // masked box: {complement mask, tile offset} of the groups that drop pixels
+    int ncomp = 0;                                         //   and their number in the current chunk
 
     STAMP(50);
     // A template of at most 32 groups (the coarse levels of a walk) is not sorted into the two lists: compacting it
     // costs more instructions than masking every group of so short a list does.
     // (decided here, from sizes alone: the direct search of a few lattice cells further down needs no entry lists either)
     const int dshift = nx * ny <= 4 ? 4 : nx * ny <= 8 ? 3 : nx * ny <= 16 ? 2 : 1;       // 2^dshift lanes per cell
+    // (it reads the staged pairs of the whole template: not where the template is taken in chunks)
     const bool direct = !SEARCH && !strips && nx * ny <= 32 && ((L.th + (1 << dshift) - 1) >> dshift) * G <= 16 &&
-                        L.x0 + (nx - 1) * L.step + 4 * G <= L.w;
+                        L.x0 + (nx - 1) * L.step + 4 * G <= L.w && !chunked && nblk == 1;
     const bool tiny = direct || (NG <= 32 && !chunked);
     unsigned sp_part = 0;
     const float rG = __builtin_amdgcn_rcpf((float)G);
@@ -506,9 +580,41 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     auto stage = [&](int blk, int ch, int nunits) -> int {
         __syncthreads();                                   // the previous level's, block's or chunk's readers of this LDS are done
         // ---- template: {P0, M} per group, |P0|^2, counts of all-kept and partly kept groups ------------------------
-        const int ut = box ? 0 : u0, Rt = box ? L.th : Rc; // the template rows staged here
+        const int ut = box && !boxm ? 0 : u0, Rt = box && !boxm ? L.th : Rc; // the template rows staged here
         const int NGb = Rt * G;                            // groups of these template rows
         int nA = 0, nB = 0;
+        if (CHUNKS && boxm) {
+            // masked box sums (stored template): P0 straight into the chunk's row-ordered array, the groups that drop
+            // pixels inside the template onto the complement list
+            const int Gp = lean_pc_pitch(G);
+            int baseC = 0;
+            for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
+                const int i = i0 + lane;
+                unsigned cm = 0;
+                const int u = (int)(((float)min(i, NGb - 1) + 0.5f) * rG), gq = min(i, NGb - 1) - u * G;
+                if (i < NGb) {
+                    const long long so = (long long)(ut + u) * L.srcw + gq * 4;
+                    const unsigned P = load4(L.patch + so, L.limit);
+                    const unsigned Mraw = load4(L.mask + so, L.limit);
+                    const int nbk = min(4, L.tw - gq * 4);
+                    const unsigned keep = nbk >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nbk)) - 1u);
+                    const unsigned nz = (((Mraw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | Mraw) & 0x80808080u;   // per byte: non-zero -> 0x80
+                    const unsigned M = ((nz >> 7) * 0xFFu) & keep;
+                    const unsigned P0 = P & M;
+                    cm = ~M & keep;
+                    pc[u * Gp + gq] = P0;
+                    if (blk == 0) sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
+                }
+                const unsigned long long bc = __ballot(cm != 0u);
+                if (cm != 0u) clist[baseC + __builtin_popcountll(bc & ((1ull << lane) - 1ull))] = ((unsigned long long)((unsigned)(u * tp + gq) * 8u) << 32) | cm;
+                baseC += __builtin_popcountll(bc);
+            }
+            for (int p2 = baseC + lane; p2 < baseC + LEAN_MAX_S; p2 += SLAM_WG) clist[p2] = 0ull;       // padding: adds nothing
+            ncomp = baseC;
+            if (blk == 0 && ch == nchunk - 1) nm = make_norms(wave_sum_u32(sp_part));       // |P0|^2 of the whole template
+            STAMP(52);
+            return 0;
+        }
         if (!L.resized) {
         for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
             const int i = i0 + lane;
@@ -709,7 +815,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
       int ch = 0;
       do {                                                  // (one pass unless the template is taken in chunks)
         if (chunked) { u0 = ch * R; Rc = min(R, L.th - u0); }
-      if (CHUNKS && ((blk == 0 && ch == 0) || (chunked && !box))) {
+      if (CHUNKS && ((blk == 0 && ch == 0) || (chunked && (!box || boxm)))) {
         const int st = stage(blk, ch, nunits);
         if (st < 0) { out.ok = false; return out; }        // (also from the rows around the peak: the position found so far is dropped with it)
         if (st == 1) break;
@@ -787,7 +893,10 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         }
         __syncthreads();
         STAMP(53);
-        if (CHUNKS && box) lean_accumulate_rows(tile, pc + u0 * lean_pc_pitch(G), acc, nunits, lean_pick_row_slices(nunits, Rc, G), Rc, G, rows_b, tp);
+        if (CHUNKS && box) {
+            lean_accumulate_rows(tile, boxm ? pc : pc + u0 * lean_pc_pitch(G), acc, nunits, lean_pick_row_slices(nunits, Rc, G), Rc, G, rows_b, tp);
+            if (boxm) lean_accumulate_dropped(tile, clist, acc, nunits, ncomp, rows_b, tp);
+        }
         else if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, rows_b, tp, o, 1);
         else lean_accumulate<1>(tile, list, marr, acc, nunits, S, na, nb, nA1, nx, tp, o, L.step);
         __syncthreads();

@@ -111,6 +111,33 @@ def test_fit_around_the_peak_of_a_search_in_blocks_and_chunks(oracle, lds):
     assert not bad, bad[:4]
 
 
+@pytest.mark.parametrize("lds", [4096, 4352, 5120])
+def test_coarse_levels_whose_template_is_taken_in_chunks(oracle, lds):
+    """Under a four-level pyramid a 53x55 template is 26x27 at sub = 2: four lattice cells, which the kernel would sum
+    straight from the image against the whole staged template - but at these budgets the template is staged in chunks,
+    so the entry lists have to do it."""
+    rng = np.random.default_rng(lds + 3 + SOAK_SEED)
+    w, h, subs, shift = 480, 360, [1.0, 2.0, 4.0, 8.0], (-3, 2)
+    f0, f1 = synth.frame(w, h, 78), synth.frame(w, h, 78, shift)
+    jobs = _interior_jobs(rng, f0, shift, [(53, 55), (47, 61), (61, 45)], 6, 64)
+    with api.Context(0) as c:
+        L = api.capi.lib()
+        api.capi.check(c.handle, L.slam_hip_set_walk_lds(c.handle, lds))
+        api.capi.check(c.handle, L.slam_hip_set_walk_chunks(c.handle, 1))
+        pyr = api.ImagePyramid(c, f1, subs)
+        try:
+            got = api.track_batch(c, pyr, jobs)
+        finally:
+            pyr.close()
+    levels = oracle.pyramid(f1, subs)
+    bad = []
+    for k, (j, g) in enumerate(zip(jobs, got)):
+        r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+        if not _same(g, r):
+            bad.append((k, j["proj"].shape, g, r))
+    assert not bad, bad[:4]
+
+
 def test_the_plain_build_leaves_large_templates_to_the_general_kernel_and_the_chunked_one_takes_them(oracle):
     rng = np.random.default_rng(5 + SOAK_SEED)
     w, h, subs, shift = 640, 480, [1.0, 3.0], (-2, 5)
