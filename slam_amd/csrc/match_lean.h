@@ -136,6 +136,32 @@ __host__ __device__ __forceinline__ int lean_mcap(int NG, int th, bool walk) {
     return walk && NG > 32 && m < cap ? m : cap;           // templates of at most 32 groups mask every entry (lean_level)
 }
 
+// dwords per template row of the resident P0 array of lean_level's box mode: rows of three groups and more start on
+// 16-byte boundaries (four groups' dwords are read at once); with fewer the rows stay packed, which keeps the in-place
+// move from the staged {P0, M} pairs (8 bytes a group) behind its own reads
+__host__ __device__ __forceinline__ int lean_pc_pitch(int G) { return G >= 3 ? (G + 3) & ~3 : G; }
+
+// Which searches of the chunk-capable builds take their window energies from box sums of the squared image (see
+// lean_level): 0 none; 1 templates without a mask (single searches: the P0 dwords of the whole template stay resident);
+// 2 masked templates of walks, stored at this level's resolution and large enough for the box sums to pay (their cost
+// grows with the cell rows, the cost of the dots they replace with strips x template groups).  (In the plain walk build
+// the same scheme, with the boxes summed out of the LDS tile, measured slower on the templates that build is for: a C2
+// walk 4347 instead of 4104 VALU instructions - 17 cell rows of prefix sums cost more than the 670 dots they replace -
+// and its mere presence in the kernel cost the C2 path 3.6 %; 31x31 templates gained 1 - 2 %.)
+#define LEAN_BOX_NONE 0
+#define LEAN_BOX_UNMASKED 1
+#define LEAN_BOX_MASKED 2
+__host__ __device__ __forceinline__ int lean_box_mode(bool search, bool has_mask, int step, bool resized, int tw, int th, int aw) {
+    if (step != 1 || aw + tw - 1 > 2 * SLAM_WG) return LEAN_BOX_NONE;
+    if (!has_mask) return search ? LEAN_BOX_UNMASKED : LEAN_BOX_NONE;
+    const int G = (tw + 3) >> 2, cols = (aw + 3) >> 2;
+    return !search && !resized && th * G * cols >= 2048 ? LEAN_BOX_MASKED : LEAN_BOX_NONE;
+}
+
+// Entries of the list of groups that drop pixels inside the template (masked box sums): every group at worst, padding
+// and read-ahead
+__host__ __device__ __forceinline__ int lean_ccap(int NG) { return NG + LEAN_MAX_S + 4; }
+
 // LDS bytes a level needs (INT_MAX: a shape this path does not take), with the window's column phase x0 & 3 at its
 // worst, so that the answer depends on sizes only and a walk can be turned away before its first level is searched.
 __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah, int step, int nx, int ny, bool resized) {
@@ -162,31 +188,12 @@ __host__ __device__ __forceinline__ int lean_need(int tw, int th, int aw, int ah
 #define LEAN_MIN_CHUNK 4
 struct LeanPlan { int bh, R; };
 
-// dwords per template row of the resident P0 array of lean_level's box mode: rows of three groups and more start on
-// 16-byte boundaries (four groups' dwords are read at once); with fewer the rows stay packed, which keeps the in-place
-// move from the staged {P0, M} pairs (8 bytes a group) behind its own reads
-__host__ __device__ __forceinline__ int lean_pc_pitch(int G) { return G >= 3 ? (G + 3) & ~3 : G; }
-
 __host__ __device__ __forceinline__ int lean_div(int n, int d) {
 #ifdef __HIP_DEVICE_COMPILE__
     return small_div(n, d);
 #else
     return n / d;
 #endif
-}
-
-// Which searches of the chunk-capable builds take their window energies from box sums of the squared image (see
-// lean_level): 0 none; 1 templates without a mask (single searches: the P0 dwords of the whole template stay resident);
-// 2 masked templates of walks, stored at this level's resolution and large enough for the box sums to pay (their cost
-// grows with the cell rows, the cost of the dots they replace with strips x template groups).
-#define LEAN_BOX_NONE 0
-#define LEAN_BOX_UNMASKED 1
-#define LEAN_BOX_MASKED 2
-__host__ __device__ __forceinline__ int lean_box_mode(bool search, bool has_mask, int step, bool resized, int tw, int th, int aw) {
-    if (step != 1 || aw + tw - 1 > 2 * SLAM_WG) return LEAN_BOX_NONE;
-    if (!has_mask) return search ? LEAN_BOX_UNMASKED : LEAN_BOX_NONE;
-    const int G = (tw + 3) >> 2, cols = (aw + 3) >> 2;
-    return !search && !resized && th * G * cols >= 2048 ? LEAN_BOX_MASKED : LEAN_BOX_NONE;
 }
 
 __host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, int cpu, int rstep, int rows_all, int bh, int R, bool resized, bool walk,
@@ -197,7 +204,7 @@ __host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, 
     int tile = (((bh - 1) * rstep + R) * tp * 8 + 15) & ~15;
     if (tile < 2 * SLAM_WG * 4) tile = 2 * SLAM_WG * 4;    // the box sums' prefix array lives there before the tile
     if (box == LEAN_BOX_MASKED)                            // the chunk's P0 dwords, its complement list (every group at worst), the tile
-        return acc + ((R * lean_pc_pitch(G) * 4 + 15) & ~15) + (NGc + LEAN_MAX_S + 4) * 8 + tile;
+        return acc + ((R * lean_pc_pitch(G) * 4 + 15) & ~15) + lean_ccap(NGc) * 8 + tile;
     if (box) {
         // no lists: the whole template's P0 dwords stay resident, staged (8 bytes a group, taps behind them) where the
         // tile goes afterwards
@@ -521,7 +528,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int cap = lean_cap(NGc);                         // room for the padding entries and for reads a few entries ahead
     // (box: no lists - the P0 dwords of the whole template, or of a chunk and its list of groups that drop pixels, take their place)
     const int list_bytes = boxm ? (R * lean_pc_pitch(G) * 4 + 15) & ~15 : box ? (L.th * lean_pc_pitch(G) * 4 + 15) & ~15 : cap * 8;
-    const int marr_bytes = boxm ? (NGc + LEAN_MAX_S + 4) * 8 : box ? 0 : (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
+    const int marr_bytes = boxm ? lean_ccap(NGc) * 8 : box ? 0 : (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
     if (SEARCH && !CHUNKS) {
         // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
         if (L.tw > 256 || L.th > 256 || L.tw * L.th > 66051 || tp > 64) { LEAN_REJECT(101); return out; }
@@ -586,6 +593,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         if (CHUNKS && boxm) {
             // masked box sums (stored template): P0 straight into the chunk's row-ordered array, the groups that drop
             // pixels inside the template onto the complement list
+            const int ccap = lean_ccap(NGc);
             const int Gp = lean_pc_pitch(G);
             int baseC = 0;
             for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
@@ -606,9 +614,12 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                     if (blk == 0) sp_part += __builtin_amdgcn_udot4(P0, P0, 0u, false);
                 }
                 const unsigned long long bc = __ballot(cm != 0u);
-                if (cm != 0u) clist[baseC + __builtin_popcountll(bc & ((1ull << lane) - 1ull))] = ((unsigned long long)((unsigned)(u * tp + gq) * 8u) << 32) | cm;
+                const int pos = baseC + __builtin_popcountll(bc & ((1ull << lane) - 1ull));
+                if (cm != 0u && pos < ccap) clist[pos] = ((unsigned long long)((unsigned)(u * tp + gq) * 8u) << 32) | cm;
                 baseC += __builtin_popcountll(bc);
             }
+            // a mask that drops pixels in more groups than a warped quadrilateral does (the plain build's list has room for those only)
+            if (baseC + LEAN_MAX_S + 3 > ccap) { LEAN_REJECT(4); return -1; }
             for (int p2 = baseC + lane; p2 < baseC + LEAN_MAX_S; p2 += SLAM_WG) clist[p2] = 0ull;       // padding: adds nothing
             ncomp = baseC;
             if (blk == 0 && ch == nchunk - 1) nm = make_norms(wave_sum_u32(sp_part));       // |P0|^2 of the whole template
