@@ -67,7 +67,7 @@ int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes);
 /* on = 1: the lean point-walk kernel also takes walks whose full-resolution level (stored template, every cell) does
  * not fit the budget above whole: the template is then searched in chunks of rows, the sums of all cells running on
  * in LDS (the reference's live shape, 81x81 descriptors in 24x24 windows, matching.cpp:243-250 with feature.cpp:133-139:
- * 15360 bytes and on = 1).  A build of the kernel with more registers: leave it off (the default) for small templates.
+ * 12800 bytes and on = 1).  A build of the kernel with more registers: leave it off (the default) for small templates.
  * The entry points that take a host job table pick budget and build themselves unless this or slam_hip_set_walk_lds
  * was called.  Results do not depend on it. */
 int slam_hip_set_walk_chunks(slam_ctx* ctx, int on);
