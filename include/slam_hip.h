@@ -443,6 +443,14 @@ int slam_hip_debug_resize(slam_ctx* ctx, const uint8_t* src, int sw, int sh, siz
  * general kernel (0 when the lean kernel is switched off by SLAM_HIP_NO_LEAN=1 or SLAM_HIP_FORCE_DIRECT=1).
  * Synchronises the stream. */
 int slam_hip_debug_walk_deferred(slam_ctx* ctx, int* out_deferred);
+/* How the lean walk kernel would take one level of a walk with `budget` bytes of LDS (host arithmetic only, no device
+ * needed; the kernel makes the same decision from the same sizes): template tw x th at that level, window aw x ah,
+ * lattice step, `resized` != 0 when the level's template is resized from the stored one, `chunks` = the kernel's build
+ * (slam_hip_set_walk_chunks).  out[0] = cell rows per block (0: the level is left to the general kernel), out[1] =
+ * template rows per chunk, out[2] = LDS bytes of that plan, out[3] = 1 / 2 when the window energies come from box sums
+ * (unmasked / masked template), else 0.  No counterpart in the reference: a planning aid for callers of the `_d` forms,
+ * who pick budget and build themselves. */
+int slam_hip_debug_walk_plan(int tw, int th, int aw, int ah, int step, int resized, int budget, int chunks, int out[4]);
 /* Library build identification: "slam_hip <version> gfx950". */
 const char* slam_hip_version(void);
 

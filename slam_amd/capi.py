@@ -147,6 +147,7 @@ SIGNATURES = {
     "slam_hip_debug_score_formulas": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P]),
     "slam_hip_debug_resize": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_size_t, _P, C.c_int, C.c_int, C.c_size_t]),
     "slam_hip_debug_walk_deferred": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "slam_hip_debug_walk_plan": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_int32)]),
     "slam_hip_version": (C.c_char_p, []),
 }
 

@@ -1278,6 +1278,27 @@ extern "C" int slam_hip_line_track_batch(slam_ctx* ctx, const slam_pyr* pyr, con
     return SLAM_HIP_OK;
 }
 
+extern "C" int slam_hip_debug_walk_plan(int tw, int th, int aw, int ah, int step, int resized, int budget, int chunks, int out[4]) {
+    if (!out || tw < 1 || th < 1 || aw < 1 || ah < 1 || step < 1 || tw > 255 || th > 255 || aw > 255 || ah > 255 || budget < 0)
+        return SLAM_HIP_EINVAL;
+    const int nx = (aw + step - 1) / step, ny = (ah + step - 1) / step;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!chunks) {
+        const int need = lean_need(tw, th, aw, ah, step, nx, ny, resized != 0);
+        if (need != INT_MAX && need <= budget) { out[0] = step == 1 ? ah : ny; out[1] = th; out[2] = need; }
+        return SLAM_HIP_OK;
+    }
+    const int box = lean_box_mode(false, true, step, resized != 0, tw, th, aw);
+    const LeanPlan pl = lean_plan(tw, th, aw, ah, step, nx, ny, resized != 0, true, budget, box);
+    if (pl.bh > 0) {
+        const int G = (tw + 3) >> 2, cols = (aw + 3) >> 2, tp = (cols + G - 1) | 1;
+        const bool strips = step == 1;
+        out[0] = pl.bh; out[1] = pl.R; out[3] = box;
+        out[2] = lean_plan_bytes(G, tp, strips ? cols : nx, strips ? 4 : 1, strips ? 1 : step, strips ? ah : ny, pl.bh, pl.R, resized != 0, true, th, box);
+    }
+    return SLAM_HIP_OK;
+}
+
 extern "C" int slam_hip_debug_walk_deferred(slam_ctx* ctx, int* out_deferred) {
     if (!ctx || !out_deferred) return SLAM_HIP_EINVAL;
     *out_deferred = 0;
