@@ -660,7 +660,8 @@ def prod_leg(api, capi, ctx, stream, dev, args, traffic):
                          "jobs_left_to_general_kernel": deferred.value, "parity": parity,
                          "walk_lds_bytes": args.prod_walk_lds or 7680, "walk_chunks": bool(args.prod_walk_lds),
                          "one_frame": {"features": nfeat, "ms": float(lat), "ms_min": lat.fastest,
-                                       "note": "launch to completion of one frame's walks (one wavefront each) between HIP events"}})
+                                       "note": "launch to completion of one frame's walks between HIP events (with the chunked build: "
+                                               "the last level of every walk in 8 bands of rows, one wavefront each)"}})
     capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 0))
     capi.check(ctx.handle, L.slam_hip_set_walk_lds(ctx.handle, 7680))      # back to the defaults
     pyr.close()

@@ -69,7 +69,9 @@ int slam_hip_set_walk_lds(slam_ctx* ctx, int bytes);
  * in LDS (the reference's live shape, 81x81 descriptors in 24x24 windows, matching.cpp:243-250 with feature.cpp:133-139:
  * 12800 bytes and on = 1).  A build of the kernel with more registers: leave it off (the default) for small templates.
  * The entry points that take a host job table pick budget and build themselves unless this or slam_hip_set_walk_lds
- * was called.  Results do not depend on it. */
+ * was called.  A batch of at most 256 walks under this build has the last level of every walk searched in bands of
+ * rows over several wavefronts (one frame's walks: a third of the latency); their records live in a buffer of the
+ * context that grows on demand.  Results do not depend on it. */
 int slam_hip_set_walk_chunks(slam_ctx* ctx, int on);
 /* Text of the last error on ctx (or of the last failed slam_hip_create when ctx is NULL). */
 const char* slam_hip_last_error_string(const slam_ctx* ctx);

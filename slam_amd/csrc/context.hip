@@ -55,6 +55,10 @@ extern "C" int slam_hip_create(int device, slam_ctx** out) {
     if (ll && atoi(ll) >= 4096 && atoi(ll) <= 65536) c->line_lean_lds_bytes = atoi(ll) & ~63;
     const char* lm = getenv("SLAM_HIP_LINE_LEAN_MIN");
     if (lm && atoi(lm) >= 1) c->line_lean_min_jobs = atoi(lm);
+    const char* wbl = getenv("SLAM_HIP_WALK_BAND_LDS_BYTES");
+    if (wbl && atoi(wbl) >= 4096 && atoi(wbl) <= 65536) c->walk_band_lds_bytes = atoi(wbl) & ~63;
+    const char* wbn = getenv("SLAM_HIP_WALK_BANDS");
+    if (wbn && atoi(wbn) >= 1 && atoi(wbn) <= 8) c->walk_bands = atoi(wbn);
     const char* wc = getenv("SLAM_HIP_WALK_CHUNKS");
     if (wc && (wc[0] == '0' || wc[0] == '1')) c->walk_chunks = wc[0] - '0';
     const char* sk = getenv("SLAM_HIP_SEARCH_LDS_KB");

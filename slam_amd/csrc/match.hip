@@ -487,9 +487,28 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
 // interior window small enough for lean_level (match_lean.h).  A job it does not cover - checked level by level, as
 // the windows depend on the results - is appended to the queue and walked again from the start by track_kernel;
 // nothing is written to `out` for it here.
-template <bool CHUNKS>
+//
+// A small batch of walks under large templates (one frame of the reference's own: 64 features with 81x81 descriptors,
+// new_image.cpp:80-82) leaves most of the chip idle while one wavefront per walk searches the full-resolution level.
+// For such batches that level is cut into `nb` bands of cell rows, one wavefront each (WALK_BAND: every band's
+// wavefront walks the levels above by itself - they are a few per cent of the work and give every band the same
+// window - and searches its rows of the last level; track_band_finish_kernel takes the first of the bands' maxima
+// in band order, the first maximum in row-major order, and searches the at most three rows around it once more for
+// the sub-pixel fit, WALK_FIT, whose neighbours may sit in another band).
+enum { WALK_WHOLE = 0, WALK_BAND = 1, WALK_FIT = 2 };
+struct WalkBand {
+    float tx, ty;            // trackedPoint before the last level (WALK_BAND) - or the walk's result when it ended above it
+    int x, y;                // the band's peak at the last level, level coordinates
+    float response, dx, dy;
+    int levels_run;          // levels searched before the last one (ended walks: all of them)
+    int state;               // 0: not covered (the general kernel walks the job), 1: band searched, 2: the walk ended above the last level
+    int pad[3];
+};
+
+template <bool CHUNKS, int MODE = WALK_WHOLE>
 __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_track_job& job, const uint8_t* __restrict__ blob,
-                                          unsigned long long blob_bytes, lds_u8* lds, int lds_total, slam_track_result& r) {
+                                          unsigned long long blob_bytes, lds_u8* lds, int lds_total, slam_track_result& r,
+                                          WalkBand* wb = nullptr, int band = 0, int nb = 1) {
     STAMP_DECL;
     STAMP(1);
     const long long pbytes = (long long)job.projw * job.projh;
@@ -545,7 +564,9 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
         }
         if (__ballot(!fits) != 0ull) { LEAN_REJECT(13); return false; }
     }
+    if (MODE == WALK_FIT) { tx = wb->tx; ty = wb->ty; levels_run = wb->levels_run; }
     for (int i = nlev - 1; i >= 0; --i) {
+        if (MODE == WALK_FIT && i > 0) continue;           // the levels above are done: their result came with the record
         STAMP_LEVEL(i);
         STAMP(2);
         const slam_level_dev& lv = pyr.lev[i];
@@ -584,9 +605,28 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
             lv.pitch > 0x7fffffffLL || ((reinterpret_cast<unsigned long long>(L.im) | (unsigned long long)lv.pitch) & 3ull) != 0) {
             LEAN_REJECT(12 + 1000 * i); return false;
         }
+        if (MODE == WALK_BAND && i == 0) {                 // this band's rows of the last level; no fit
+            if (rh < nb) { LEAN_REJECT(14); return false; }
+            const int y0b = small_div_u(band * rh, nb), y1b = small_div_u((band + 1) * rh, nb);
+            if (L.amask) L.amask += y0b * rw;
+            L.y0 += y0b; L.ah = y1b - y0b;
+            const LeanOut o = lean_level<false, CHUNKS>(L, lds, lds_total, false, -1e300 STAMP_PASS);
+            if (!o.ok) return false;
+            wb->tx = tx; wb->ty = ty; wb->x = o.x; wb->y = o.y; wb->response = o.response; wb->dx = 0.f; wb->dy = 0.f;
+            wb->levels_run = levels_run; wb->state = 1;
+            return true;
+        }
+        if (MODE == WALK_FIT) {                            // the rows around the peak the bands found: it is their first maximum too
+            const int ly = wb->y - ry;                     // (a level's result is cell + window origin: matching.cpp:225-226)
+            const int r0 = max(ly - 1, 0), r1 = min(ly + 1, rh - 1);
+            if (ly < 0 || ly >= rh) { LEAN_REJECT(15); return false; }
+            if (L.amask) L.amask += r0 * rw;
+            L.y0 += r0; L.ah = r1 - r0 + 1;
+        }
         // feature.cpp:151-152: the level that ends the walk also reports the sub-pixel fit
         const LeanOut o = lean_level<false, CHUNKS>(L, lds, lds_total, i == 0, stop_below STAMP_PASS);
         if (!o.ok) return false;
+        if (MODE == WALK_FIT && (o.x != wb->x || o.y != wb->y)) { LEAN_REJECT(16); return false; }
         levels_run++;
         response = o.response; sdx = o.dx; sdy = o.dy;
         tx = __fmul_rn((float)o.x, sub);         // feature.cpp:150
@@ -594,6 +634,11 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
         if ((double)response < stop_below) break;   // feature.cpp:151-152
     }
     STAMP(30);
+    if (MODE == WALK_BAND) {                               // the walk ended above the last level: every band holds its result
+        wb->tx = tx; wb->ty = ty; wb->x = 0; wb->y = 0; wb->response = response; wb->dx = sdx; wb->dy = sdy;
+        wb->levels_run = levels_run; wb->state = 2;
+        return true;
+    }
     r.x = (int)tx; r.y = (int)ty; r.response = response; r.dx = sdx; r.dy = sdy; r.levels_run = levels_run;
     r.status = SLAM_HIP_OK;
     return true;
@@ -616,6 +661,56 @@ __global__ __launch_bounds__(SLAM_WG, CHUNKS ? SLAM_MIN_WAVES_CHUNKS : SLAM_MIN_
     const slam_track_job job = jobs[j];
     slam_track_result r;
     const bool done = lean_walk<CHUNKS>(pyr, job, blob, blob_bytes, lds, lds_total, r);
+    if (threadIdx.x == 0) {
+        if (done) out[j] = r;
+        else queue_put(queue, j);
+    }
+}
+
+// Band b of walk j (workgroup j * nb + b): the levels above the last one, then the band's rows of the last level.
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_CHUNKS) void track_band_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob, unsigned long long blob_bytes,
+                                                        WalkBand* __restrict__ bands, int nb, int lds_total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const int j = (int)blockIdx.x / nb, band = (int)blockIdx.x - j * nb;
+    if (j >= njobs) return;
+    const slam_track_job job = jobs[j];
+    slam_track_result r;
+    WalkBand w;
+    w.tx = 0.f; w.ty = 0.f; w.x = 0; w.y = 0; w.response = 0.f; w.dx = 0.f; w.dy = 0.f; w.levels_run = 0; w.state = 0;
+    w.pad[0] = w.pad[1] = w.pad[2] = 0;
+    if (!lean_walk<true, WALK_BAND>(pyr, job, blob, blob_bytes, lds, lds_total, r, &w, band, nb)) w.state = 0;
+    if (threadIdx.x == 0) bands[(size_t)j * nb + band] = w;
+}
+
+// The bands of walk j put together: its result, or its index on the queue of the general kernel when a band was not covered.
+__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_CHUNKS) void track_band_finish_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
+                                                        int njobs, const uint8_t* __restrict__ blob, unsigned long long blob_bytes,
+                                                        const WalkBand* __restrict__ bands, int nb,
+                                                        slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    lds_u8* lds = (lds_u8*)dyn_lds;
+    const int j = blockIdx.x;
+    if (j >= njobs) return;
+    const WalkBand* bj = bands + (size_t)j * nb;
+    WalkBand best = bj[0];
+    bool all = best.state != 0;
+    for (int k = 1; k < nb; k++) {                         // wave-uniform loads
+        const WalkBand bk = bj[k];
+        all = all && bk.state == best.state;
+        if (bk.state == 1 && bk.response > best.response) best = bk;      // strict: the first band holding the maximum keeps it
+    }
+    bool done = false;
+    slam_track_result r;
+    if (all && best.state == 2) {
+        r.x = (int)best.tx; r.y = (int)best.ty; r.response = best.response; r.dx = best.dx; r.dy = best.dy;
+        r.levels_run = best.levels_run; r.status = SLAM_HIP_OK;
+        done = true;
+    } else if (all && best.state == 1) {
+        const slam_track_job job = jobs[j];
+        done = lean_walk<true, WALK_FIT>(pyr, job, blob, blob_bytes, lds, lds_total, r, &best, 0, nb);
+    }
     if (threadIdx.x == 0) {
         if (done) out[j] = r;
         else queue_put(queue, j);
@@ -876,6 +971,22 @@ int slam_queue_launched(slam_ctx* ctx, int* queue, int njobs, hipError_t e) {
     return slam_set_error(ctx, SLAM_HIP_EHIP, "launch of the general kernel failed: %s", hipGetErrorString(e));
 }
 
+// Room for the band records of a small batch (line walks, point walks) in the context's buffer, grown on demand like
+// the walk queue.  On failure the buffer is gone and the caller goes without bands.
+int slam_bands_reserve(slam_ctx* ctx, size_t need) {
+    if (need <= ctx->bands_bytes) return SLAM_HIP_OK;
+    SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_bands) { SLAM_HIP_CHECK(ctx, hipFree(ctx->d_bands)); ctx->d_bands = nullptr; ctx->bands_bytes = 0; }
+    const size_t want = need * 2 + 4096;
+    if (hipMalloc(&ctx->d_bands, want) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->d_bands = nullptr;
+        return SLAM_HIP_ENOMEM;
+    }
+    ctx->bands_bytes = want;
+    return SLAM_HIP_OK;
+}
+
 int check_pyr(slam_ctx* ctx, const slam_pyr* pyr, const char* who) {
     if (!pyr || !pyr->built) return slam_set_error(ctx, SLAM_HIP_EINVAL, "%s: pyramid not built", who);
     if (pyr->device != ctx->device) return slam_set_error(ctx, SLAM_HIP_EINVAL, "%s: pyramid belongs to device %d", who, pyr->device);
@@ -1131,6 +1242,24 @@ int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* 
     // a queue shared by every context of the device (the no-alloc entry point) is cleared first: another context's
     // failed or overlapping launch must not leave its count or its entries behind
     if (clear_first) SLAM_HIP_CHECK(ctx, hipMemsetAsync(queue, 0, (SLAM_DEFER_LIST + (size_t)njobs) * sizeof(int), ctx->stream));
+    // A small batch under the second build (large templates) has the last level of every walk cut into bands of rows
+    // (track_band_kernel + track_band_finish_kernel); not where nothing may be allocated (the bands' records live in a
+    // buffer of the context that grows on demand).
+    int nb = 1;
+    if (chunks && !clear_first) {
+        nb = ctx->walk_bands > 0 ? ctx->walk_bands : (njobs <= 256 ? 2048 / njobs : 1);
+        nb = nb < 1 ? 1 : (nb > 8 ? 8 : nb);
+        if (nb > 1 && slam_bands_reserve(ctx, (size_t)njobs * nb * sizeof(WalkBand)) != SLAM_HIP_OK) nb = 1;
+    }
+    if (nb > 1) {
+        // (a batch this small does not fill the chip: LDS per wavefront is no concern, fewer chunks are what counts)
+        const int bl = ctx->walk_band_lds_bytes > lds ? ctx->walk_band_lds_bytes : lds;
+        hipLaunchKernelGGL(track_band_kernel, dim3(njobs * nb), dim3(SLAM_WG), bl, ctx->stream, pyr->dev, d_jobs, njobs,
+                           d_blob, (unsigned long long)blob_bytes, (WalkBand*)ctx->d_bands, nb, bl);
+        SLAM_HIP_CHECK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(track_band_finish_kernel, dim3(njobs), dim3(SLAM_WG), bl, ctx->stream, pyr->dev, d_jobs, njobs,
+                           d_blob, (unsigned long long)blob_bytes, (const WalkBand*)ctx->d_bands, nb, d_out, bl, queue);
+    } else
     // Two builds of the lean kernel: the plain one takes walks whose every level fits the budget whole; the other also
     // takes full-resolution levels with templates too large for that, in blocks of cell rows and chunks of template rows (lean_plan), at
     // the price of more registers - the caller, or slam_size_walk_lds for a host job table, picks it for such shapes.
@@ -1225,17 +1354,7 @@ extern "C" int slam_hip_line_track_batch_d(slam_ctx* ctx, const slam_pyr* pyr, c
     const bool lean = nb == 1 && !ctx->force_direct && !ctx->no_lean && njobs >= ctx->line_lean_min_jobs;
     LineBand* d_bands = nullptr;
     if (nb > 1 || lean) {
-        const size_t need = (size_t)njobs * nb * sizeof(LineBand);
-        if (need > ctx->bands_bytes) {                         // grown on demand, like the walk queue
-            SLAM_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->d_bands) { SLAM_HIP_CHECK(ctx, hipFree(ctx->d_bands)); ctx->d_bands = nullptr; ctx->bands_bytes = 0; }
-            const size_t want = need * 2 + 4096;
-            if (hipMalloc(&ctx->d_bands, want) != hipSuccess) {
-                (void)hipGetLastError();
-                ctx->d_bands = nullptr;
-                nb = 1;                                        // no room for the bands: one wavefront per line
-            } else ctx->bands_bytes = want;
-        }
+        if (slam_bands_reserve(ctx, (size_t)njobs * nb * sizeof(LineBand)) != SLAM_HIP_OK) nb = 1;     // no room for the bands: one wavefront per line
         d_bands = (LineBand*)ctx->d_bands;
     }
     if (lean && d_bands) {

@@ -596,7 +596,8 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             const int ccap = lean_ccap(NGc);
             const int Gp = lean_pc_pitch(G);
             int baseC = 0;
-            for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {
+#pragma unroll 4
+            for (int i0 = 0; i0 < NGb; i0 += SLAM_WG) {             // (unrolled: the loads of four passes in flight at once)
                 const int i = i0 + lane;
                 unsigned cm = 0;
                 const int u = (int)(((float)min(i, NGb - 1) + 0.5f) * rG), gq = min(i, NGb - 1) - u * G;
@@ -847,6 +848,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                     box_e0 += b0 * b0 - a0 * a0; box_e1 += b1 * b1 - a1 * a1;
                 } else if (box_y != y) {                    // from scratch: the first block, or the rows around the peak
                     box_e0 = 0; box_e1 = 0;
+#pragma unroll 8
                     for (int r = 0; r < L.th; r++) {
                         const unsigned a0 = c0[(unsigned)(y + r) * L.ipitch], a1 = c1[(unsigned)(y + r) * L.ipitch];
                         box_e0 += a0 * a0; box_e1 += a1 * a1;

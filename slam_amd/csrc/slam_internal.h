@@ -29,6 +29,8 @@ struct slam_ctx {
     int lean_lds_once = 0;             // budget of the next walk launch only (slam_size_walk_lds), 0 = lean_lds_bytes
     int line_lean_lds_bytes = 12800;   // LDS per line of line_lean_coarse_kernel: 10 granules, 12 lines per CU (SLAM_HIP_LINE_LEAN_LDS_BYTES)
     int line_lean_min_jobs = 1024;     // line batches from this size on search their coarsest level with the lean core (SLAM_HIP_LINE_LEAN_MIN)
+    int walk_band_lds_bytes = 65536;   // LDS per wavefront of the banded walk kernels (SLAM_HIP_WALK_BAND_LDS_BYTES): such batches do not fill the chip
+    int walk_bands = 0;                // bands per walk of small batches under the second build, 0 = by batch size (SLAM_HIP_WALK_BANDS)
     int walk_chunks = 0;               // lean walk kernel built with template chunks (slam_hip_set_walk_chunks, SLAM_HIP_WALK_CHUNKS)
     int walk_chunks_once = 0;          // the same for the next walk launch only (slam_size_walk_lds)
     int no_lean = 0;                   // SLAM_HIP_NO_LEAN=1: walks and searches skip the lean kernels (cross-check of them)

@@ -138,6 +138,44 @@ def test_coarse_levels_whose_template_is_taken_in_chunks(oracle, lds):
     assert not bad, bad[:4]
 
 
+@pytest.mark.parametrize("bands", [1, 2, 3, 5, 8])
+def test_small_batches_have_their_last_level_cut_into_bands(oracle, bands, monkeypatch):
+    """A small batch under the second build (by batch size; forced here through SLAM_HIP_WALK_BANDS) searches the last
+    level of every walk in bands of rows, one wavefront each, and fits around the first of the bands' maxima: the
+    oracle's results at every band count - walks that end above the last level, walks over the image border (left to
+    the general kernel), single-level pyramids and constant templates included."""
+    monkeypatch.setenv("SLAM_HIP_WALK_BANDS", str(bands))
+    rng = np.random.default_rng(31 + SOAK_SEED)
+    w, h, shift = 640, 480, (3, -2)
+    f0, f1 = synth.frame(w, h, 91 + SOAK_SEED), synth.frame(w, h, 91 + SOAK_SEED, shift)
+    nbad = 0
+    with api.Context(0) as c:
+        L = api.capi.lib()
+        api.capi.check(c.handle, L.slam_hip_set_walk_lds(c.handle, 12800))
+        api.capi.check(c.handle, L.slam_hip_set_walk_chunks(c.handle, 1))
+        for subs in ([1.0, 3.0], [1.0], [1.0, 2.0, 4.0]):
+            jobs = _interior_jobs(rng, f0, shift, [(81, 81), (45, 33), (21, 21), (64, 80)], 3, 60)
+            jobs.append(dict(jobs[0], threshold=1.5))                                     # ends on the coarsest level
+            jobs.append(dict(jobs[1], px=3.0, py=h - 2.0))                                # windows over the border
+            jobs.append(dict(jobs[2], proj=np.full_like(jobs[2]["proj"], 7)))             # every score equal: the first cell wins
+            jobs.append(dict(jobs[3], proj_mask=(rng.random(jobs[3]["proj"].shape) < 0.5).astype(np.uint8)))   # a noise mask
+            pyr = api.ImagePyramid(c, f1, subs)
+            try:
+                got = api.track_batch(c, pyr, jobs)
+                left = api.debug_walk_deferred(c)
+            finally:
+                pyr.close()
+            if DEFAULT_KERNEL_SPLIT:
+                assert left <= 2, left                     # the walk over the border; the constant template's scores may all be NaN-free
+            levels = oracle.pyramid(f1, subs)
+            for k, (j, g) in enumerate(zip(jobs, got)):
+                r = oracle.track(levels, subs, j["proj"], j["proj_mask"], j["px"], j["py"], j["threshold"], j["stride"])
+                if not _same(g, r):
+                    nbad += 1
+                    print(bands, subs, k, j["proj"].shape, g, r)
+    assert nbad == 0
+
+
 def test_the_plain_build_leaves_large_templates_to_the_general_kernel_and_the_chunked_one_takes_them(oracle):
     rng = np.random.default_rng(5 + SOAK_SEED)
     w, h, subs, shift = 640, 480, [1.0, 3.0], (-2, 5)
