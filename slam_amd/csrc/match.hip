@@ -317,6 +317,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LEAN_SEARCH) void match_lea
         L.patch = blob + job.patch_off; L.limit = blob + blob_bytes;
         L.mask = job.pmask_off != -1 ? blob + job.pmask_off : nullptr;
         L.mt = job.pmask_off == -1;
+        L.own0 = 0; L.own1 = INT_MAX;
         L.x0 = job.ax - job.pw / 2; L.y0 = job.ay - job.ph / 2;                       // matching.cpp:38-39
         L.aw = job.aw; L.ah = job.ah;
         L.step = L.mt ? 1 : job.stride;
@@ -492,15 +493,15 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES) void track_kernel(slam_pyr
 // new_image.cpp:80-82) leaves most of the chip idle while one wavefront per walk searches the full-resolution level.
 // For such batches that level is cut into `nb` bands of cell rows, one wavefront each (WALK_BAND: every band's
 // wavefront walks the levels above by itself - they are a few per cent of the work and give every band the same
-// window - and searches its rows of the last level; track_band_finish_kernel takes the first of the bands' maxima
-// in band order, the first maximum in row-major order, and searches the at most three rows around it once more for
-// the sub-pixel fit, WALK_FIT, whose neighbours may sit in another band).
-enum { WALK_WHOLE = 0, WALK_BAND = 1, WALK_FIT = 2 };
+// window - and searches its rows of the last level together with one row of its neighbours on either side: only its
+// own rows compete for the maximum, the neighbours' are there for the sub-pixel fit of a peak on the band's edge;
+// track_band_finish_kernel takes the first of the bands' maxima in band order, the first maximum in row-major order).
+enum { WALK_WHOLE = 0, WALK_BAND = 1 };
 struct WalkBand {
-    float tx, ty;            // trackedPoint before the last level (WALK_BAND) - or the walk's result when it ended above it
+    float tx, ty;            // trackedPoint after the walk's last level, from this band's peak - or where the walk ended above it
     int x, y;                // the band's peak at the last level, level coordinates
     float response, dx, dy;
-    int levels_run;          // levels searched before the last one (ended walks: all of them)
+    int levels_run;
     int state;               // 0: not covered (the general kernel walks the job), 1: band searched, 2: the walk ended above the last level
     int pad[3];
 };
@@ -526,6 +527,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
     L.patch = blob + job.proj_off; L.mask = blob + job.mask_off; L.limit = blob + blob_bytes;
     L.srcw = job.projw; L.srch = job.projh;
     L.mt = false;                               // walks carry a patch mask: the F32 formula (matching.cpp:70-72)
+    L.own0 = 0; L.own1 = INT_MAX;
     const double stop_below = __dmul_rn(0.67, (double)job.threshold);           // feature.cpp:151
     float tx = job.px, ty = job.py;             // trackedPoint (feature.cpp:122)
     float response = 0.f, sdx = 0.f, sdy = 0.f;
@@ -564,9 +566,7 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
         }
         if (__ballot(!fits) != 0ull) { LEAN_REJECT(13); return false; }
     }
-    if (MODE == WALK_FIT) { tx = wb->tx; ty = wb->ty; levels_run = wb->levels_run; }
     for (int i = nlev - 1; i >= 0; --i) {
-        if (MODE == WALK_FIT && i > 0) continue;           // the levels above are done: their result came with the record
         STAMP_LEVEL(i);
         STAMP(2);
         const slam_level_dev& lv = pyr.lev[i];
@@ -605,28 +605,23 @@ __device__ __forceinline__ bool lean_walk(const slam_pyr_dev& pyr, const slam_tr
             lv.pitch > 0x7fffffffLL || ((reinterpret_cast<unsigned long long>(L.im) | (unsigned long long)lv.pitch) & 3ull) != 0) {
             LEAN_REJECT(12 + 1000 * i); return false;
         }
-        if (MODE == WALK_BAND && i == 0) {                 // this band's rows of the last level; no fit
+        if (MODE == WALK_BAND && i == 0) {                 // this band's rows of the last level, and a row either side for the fit
             if (rh < nb) { LEAN_REJECT(14); return false; }
             const int y0b = small_div_u(band * rh, nb), y1b = small_div_u((band + 1) * rh, nb);
-            if (L.amask) L.amask += y0b * rw;
-            L.y0 += y0b; L.ah = y1b - y0b;
-            const LeanOut o = lean_level<false, CHUNKS>(L, lds, lds_total, false, -1e300 STAMP_PASS);
-            if (!o.ok) return false;
-            wb->tx = tx; wb->ty = ty; wb->x = o.x; wb->y = o.y; wb->response = o.response; wb->dx = 0.f; wb->dy = 0.f;
-            wb->levels_run = levels_run; wb->state = 1;
-            return true;
-        }
-        if (MODE == WALK_FIT) {                            // the rows around the peak the bands found: it is their first maximum too
-            const int ly = wb->y - ry;                     // (a level's result is cell + window origin: matching.cpp:225-226)
-            const int r0 = max(ly - 1, 0), r1 = min(ly + 1, rh - 1);
-            if (ly < 0 || ly >= rh) { LEAN_REJECT(15); return false; }
+            const int r0 = max(y0b - 1, 0), r1 = min(y1b + 1, rh);
             if (L.amask) L.amask += r0 * rw;
-            L.y0 += r0; L.ah = r1 - r0 + 1;
+            L.y0 += r0; L.ah = r1 - r0;
+            L.own0 = y0b - r0; L.own1 = y1b - r0;
+            const LeanOut o = lean_level<false, CHUNKS>(L, lds, lds_total, true, stop_below STAMP_PASS);
+            if (!o.ok) return false;
+            wb->tx = __fmul_rn((float)o.x, sub); wb->ty = __fmul_rn((float)o.y, sub);      // feature.cpp:150
+            wb->x = o.x; wb->y = o.y; wb->response = o.response; wb->dx = o.dx; wb->dy = o.dy;
+            wb->levels_run = levels_run + 1; wb->state = 1;
+            return true;
         }
         // feature.cpp:151-152: the level that ends the walk also reports the sub-pixel fit
         const LeanOut o = lean_level<false, CHUNKS>(L, lds, lds_total, i == 0, stop_below STAMP_PASS);
         if (!o.ok) return false;
-        if (MODE == WALK_FIT && (o.x != wb->x || o.y != wb->y)) { LEAN_REJECT(16); return false; }
         levels_run++;
         response = o.response; sdx = o.dx; sdy = o.dy;
         tx = __fmul_rn((float)o.x, sub);         // feature.cpp:150
@@ -685,36 +680,24 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_CHUNKS) void track_band_ker
 }
 
 // The bands of walk j put together: its result, or its index on the queue of the general kernel when a band was not covered.
-__global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_CHUNKS) void track_band_finish_kernel(slam_pyr_dev pyr, const slam_track_job* __restrict__ jobs,
-                                                        int njobs, const uint8_t* __restrict__ blob, unsigned long long blob_bytes,
-                                                        const WalkBand* __restrict__ bands, int nb,
-                                                        slam_track_result* __restrict__ out, int lds_total, int* __restrict__ queue) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    lds_u8* lds = (lds_u8*)dyn_lds;
-    const int j = blockIdx.x;
+__global__ void track_band_finish_kernel(const WalkBand* __restrict__ bands, int njobs, int nb, slam_track_result* __restrict__ out,
+                                         int* __restrict__ queue) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= njobs) return;
     const WalkBand* bj = bands + (size_t)j * nb;
     WalkBand best = bj[0];
     bool all = best.state != 0;
-    for (int k = 1; k < nb; k++) {                         // wave-uniform loads
+    for (int k = 1; k < nb; k++) {
         const WalkBand bk = bj[k];
         all = all && bk.state == best.state;
         if (bk.state == 1 && bk.response > best.response) best = bk;      // strict: the first band holding the maximum keeps it
     }
-    bool done = false;
-    slam_track_result r;
-    if (all && best.state == 2) {
+    if (all) {
+        slam_track_result r;
         r.x = (int)best.tx; r.y = (int)best.ty; r.response = best.response; r.dx = best.dx; r.dy = best.dy;
         r.levels_run = best.levels_run; r.status = SLAM_HIP_OK;
-        done = true;
-    } else if (all && best.state == 1) {
-        const slam_track_job job = jobs[j];
-        done = lean_walk<true, WALK_FIT>(pyr, job, blob, blob_bytes, lds, lds_total, r, &best, 0, nb);
-    }
-    if (threadIdx.x == 0) {
-        if (done) out[j] = r;
-        else queue_put(queue, j);
-    }
+        out[j] = r;
+    } else queue_put(queue, j);
 }
 
 // A small batch of line walks (the reference tracks three lines per frame, new_image.cpp:80) leaves most of the chip
@@ -819,6 +802,7 @@ __global__ __launch_bounds__(SLAM_WG, SLAM_MIN_WAVES_LINE_LEAN) void line_lean_c
             if (L.resized) { L.scx = resize_scale(job.dw, L.tw); L.scy = resize_scale(job.dh, L.th); }
             L.patch = blob + job.desc_off; L.mask = nullptr; L.limit = blob + blob_bytes;
             L.mt = true;
+            L.own0 = 0; L.own1 = INT_MAX;
             L.x0 = job.ax - L.tw / 2; L.y0 = job.ay - L.th / 2;                       // matching.cpp:38-39
             L.aw = job.aw; L.ah = job.ah;
             L.step = 1;
@@ -1257,8 +1241,8 @@ int slam_launch_track(slam_ctx* ctx, const slam_pyr* pyr, const slam_track_job* 
         hipLaunchKernelGGL(track_band_kernel, dim3(njobs * nb), dim3(SLAM_WG), bl, ctx->stream, pyr->dev, d_jobs, njobs,
                            d_blob, (unsigned long long)blob_bytes, (WalkBand*)ctx->d_bands, nb, bl);
         SLAM_HIP_CHECK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(track_band_finish_kernel, dim3(njobs), dim3(SLAM_WG), bl, ctx->stream, pyr->dev, d_jobs, njobs,
-                           d_blob, (unsigned long long)blob_bytes, (const WalkBand*)ctx->d_bands, nb, d_out, bl, queue);
+        hipLaunchKernelGGL(track_band_finish_kernel, dim3((njobs + SLAM_WG - 1) / SLAM_WG), dim3(SLAM_WG), 0, ctx->stream,
+                           (const WalkBand*)ctx->d_bands, njobs, nb, d_out, queue);
     } else
     // Two builds of the lean kernel: the plain one takes walks whose every level fits the budget whole; the other also
     // takes full-resolution levels with templates too large for that, in blocks of cell rows and chunks of template rows (lean_plan), at

@@ -85,6 +85,8 @@ struct LeanLevel {           // wave-uniform description of one level's search
     int srcw, srch;
     bool resized;            // template resized to (tw, th) on the fly (feature.cpp:130-131)
     bool mt;                 // scores by cv::matchTemplate's normalisation (matching.cpp:151-153: the modes without a patch mask)
+    int own0, own1;          // chunk-capable builds: only cells of rows own0 <= y < own1 compete for the maximum (a band of a window
+                             //   searched with a row of its neighbours on either side: the fit around a peak on the band's edge reads them)
     double scx, scy;
 };
 
@@ -579,6 +581,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     int u0 = 0, Rc = L.th;                                  // the template rows the lists and the tile hold
     int lx = 0, ly = 0;
     float bv = 0.f;
+    auto own = [&](int y) { return !CHUNKS || (y >= L.own0 && y < L.own1); };
     unsigned box_e0 = 0, box_e1 = 0;                        // energies of pixel columns 2 * lane and 2 * lane + 1
     int box_y = -2;                                         // the cell row they belong to
     // Template rows -> {P0, M} pairs -> entry lists (or, for a handful of lattice cells, the sums themselves).  The plain
@@ -926,7 +929,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             if (lane < ncell) {
                 const int cy = (int)(((float)lane + 0.5f) * rnx), cx = lane - cy * nx;
                 const int x = cx * L.step, y = (r0 + cy) * L.step;
-                if (!(L.amask && L.amask[y * L.aw + x] == 0))
+                if (!(L.amask && L.amask[y * L.aw + x] == 0) && own(y))
                     best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : lane, nm, mt), (y << 16) | x);
             }
         } else if (ncell <= NQ * SLAM_WG && nm.tn > 0.0) {
@@ -944,7 +947,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                     const int x = cx * L.step, y = (r0 + cy) * L.step;
                     ai = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                     key = (y << 16) | x;
-                    return !(L.amask && L.amask[y * L.aw + x] == 0);
+                    return !(L.amask && L.amask[y * L.aw + x] == 0) && own(y);
                 };
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
@@ -980,7 +983,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                         const int i = q * SLAM_WG + lane;
                         const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                         const int x = cx * L.step, y = (r0 + cy) * L.step;
-                        if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0)) {
+                        if (i < ncell && !(L.amask && L.amask[y * L.aw + x] == 0) && own(y)) {
                             ai[q] = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                             key[q] = (y << 16) | x;
                             const unsigned CC = acc[2 * ai[q]], SI = acc[2 * ai[q] + 1];
@@ -1008,7 +1011,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             for (int i = lane; i < ncell; i += SLAM_WG) {
                 const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                 const int x = cx * L.step, y = (r0 + cy) * L.step;
-                if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+                if ((L.amask && L.amask[y * L.aw + x] == 0) || !own(y)) continue;
                 const int ai = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                 const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
                 float est = -FLT_MAX;
@@ -1029,7 +1032,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
                 for (int i = lane; i < ncell; i += SLAM_WG) {
                     const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                     const int x = cx * L.step, y = (r0 + cy) * L.step;
-                    if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+                    if ((L.amask && L.amask[y * L.aw + x] == 0) || !own(y)) continue;
                     const int ai = strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i;
                     const unsigned CC = acc[2 * ai], SI = acc[2 * ai + 1];
                     float est = -FLT_MAX;
@@ -1042,7 +1045,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             for (int i = lane; i < ncell; i += SLAM_WG) {
                 const int cy = (int)(((float)i + 0.5f) * rnx), cx = i - cy * nx;
                 const int x = cx * L.step, y = (r0 + cy) * L.step;
-                if (L.amask && L.amask[y * L.aw + x] == 0) continue;
+                if ((L.amask && L.amask[y * L.aw + x] == 0) || !own(y)) continue;
                 best_update(b, lean_score(acc, strips ? lean_strip_cell(o + x, cy, rows_b, nunits) : i, nm, mt), (y << 16) | x);
             }
         }
