@@ -80,6 +80,36 @@ def test_one_captured_walk_replays_like_the_eager_call(entry):
             d_jobs.free(); d_blob.free(); d_out.free(); pyr.close()
 
 
+def test_one_captured_walk_in_bands_replays_like_the_eager_call(monkeypatch):
+    """The second walk build with the last level in bands of rows (forced for this batch size): band kernel, finish kernel
+    and the general kernel over the queue, captured once and replayed; the band records live in a buffer the eager call
+    before the capture has grown."""
+    import torch
+    import bench
+    from slam_amd import api, capi
+    monkeypatch.setenv("SLAM_HIP_WALK_BANDS", "4")
+    L = capi.lib()
+    stream = torch.cuda.Stream(device=torch.device("cuda", 0))
+    with api.Context(0, stream=stream.cuda_stream) as ctx:
+        capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 1))
+        frames, jobs, blob = _walks(6, 932)
+        pyr = api.ImagePyramid(ctx, frames, bench.SUBS)
+        d_jobs = api.DeviceBuffer(ctx, host=jobs.view(np.uint8).reshape(-1))
+        d_blob = api.DeviceBuffer(ctx, host=blob)
+        nbytes = len(jobs) * bench.TRACK_RES_DT.itemsize
+        d_out = api.DeviceBuffer(ctx, nbytes=nbytes, fill=0xAB)
+        try:
+            call = lambda: L.slam_hip_track_batch_d(ctx.handle, pyr.handle, d_jobs.ptr, len(jobs), d_blob.ptr, blob.size, d_out.ptr)
+            want = _replay_against_eager(ctx, stream, call, d_out, nbytes).view(bench.TRACK_RES_DT)
+            assert (want["status"] == 0).all() and (want["levels_run"] >= 1).all()
+            capi.check(ctx.handle, L.slam_hip_set_walk_chunks(ctx.handle, 0))          # the plain build gives the same records
+            capi.check(ctx.handle, call())
+            ctx.synchronize()
+            assert np.array_equal(d_out.get().view(bench.TRACK_RES_DT), want)
+        finally:
+            d_jobs.free(); d_blob.free(); d_out.free(); pyr.close()
+
+
 def test_one_captured_batch_of_single_searches_replays_like_the_eager_call():
     import torch
     import bench
