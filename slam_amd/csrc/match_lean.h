@@ -206,11 +206,11 @@ __host__ __device__ __forceinline__ int lean_plan_bytes(int G, int tp, int upr, 
     int tile = (((bh - 1) * rstep + R) * tp * 8 + 15) & ~15;
     if (tile < 2 * SLAM_WG * 4) tile = 2 * SLAM_WG * 4;    // the box sums' prefix array lives there before the tile
     if (box == LEAN_BOX_MASKED)                            // the chunk's P0 dwords, its complement list (every group at worst), the tile
-        return acc + ((R * lean_pc_pitch(G) * 4 + 15) & ~15) + lean_ccap(NGc) * 8 + tile;
+        return acc + (((R + 1) * lean_pc_pitch(G) * 4 + 15) & ~15) + lean_ccap(NGc) * 8 + tile;
     if (box) {
         // no lists: the whole template's P0 dwords stay resident, staged (8 bytes a group, taps behind them) where the
         // tile goes afterwards
-        const int NG = th * G, keep = (th * lean_pc_pitch(G) * 4 + 15) & ~15;
+        const int NG = th * G, keep = ((th + 1) * lean_pc_pitch(G) * 4 + 15) & ~15;      // (+ an all-zero row: lean_accumulate_rows2)
         const int stage = NG * 8 + (resized ? (G * 4 + th) * 8 : 0);
         return acc + (keep + tile > stage ? keep + tile : stage);
     }
@@ -425,6 +425,69 @@ __device__ __forceinline__ void lean_accumulate_rows(const lds_u8* tile, const l
     }
 }
 
+// The same numerators with two cell rows per unit: the window read of tile row 2m + t serves template row t for cell
+// row 2m and template row t - 1 for cell row 2m + 1 - ten VALU and one and a half LDS instructions per eight dots where
+// a unit of one row takes twelve and two and a half.  Tasks are (slice, strip, row pair); a slice takes the template
+// rows [a, b) of the chunk and with them the tile rows a .. b: on the first only the upper cell row counts, on the last
+// only the lower one (the other gets the all-zero row `zrow` of P0 dwords).  An odd last row pairs with nothing.
+__device__ __forceinline__ void lean_accumulate_rows2(const lds_u8* tile, const lds_u32* pc, const lds_u32* zrow, lds_u32* acc, int nunits,
+                                                      int Rc, int G, int rows, int tp) {
+    const int lane = lane_here();
+    const int npairs = (rows + 1) >> 1, upr = nunits / rows;                       // (wave-uniform: scalar division)
+    const int nu2 = upr * npairs;
+    int S = nu2 >= 33 ? 1 : min(min(LEAN_MAX_S, SLAM_WG / nu2), max(Rc >> 2, 1));
+    const int per = (Rc + S - 1) / S;                                              // template rows per slice
+    S = (Rc + per - 1) / per;
+    const int ntask = nu2 * S;
+    const int Gp = lean_pc_pitch(G);
+    const float rnu = __builtin_amdgcn_rcpf((float)nu2), rdp = __builtin_amdgcn_rcpf((float)npairs);
+    for (int t0 = 0; t0 < ntask; t0 += SLAM_WG) {
+        const int task = min(t0 + lane, ntask - 1);        // surplus lanes repeat the last task and do not flush
+        const int slice = (int)(((float)task + 0.5f) * rnu), unit2 = task - slice * nu2;
+        const int uq = (int)(((float)unit2 + 0.5f) * rdp), m = unit2 - uq * npairs;  // strip, row pair
+        const bool has1 = 2 * m + 1 < rows;
+        const int a = slice * per, b = min(a + per, Rc);
+        const lds_u8* tl = tile + (unsigned)((2 * m + a) * tp + uq) * 8u;
+        const lds_u32* pr = pc + a * Gp;
+        unsigned c0[4] = {0u, 0u, 0u, 0u}, c1[4] = {0u, 0u, 0u, 0u};
+        auto group = [&](unsigned P0, unsigned P1, const lds_u8* wp) {
+            const unsigned long long w03 = *reinterpret_cast<const lds_u64*>(wp);
+            const unsigned w0 = (unsigned)w03, w3 = (unsigned)(w03 >> 32);
+            const unsigned w1 = __builtin_amdgcn_perm(w3, w0, 0x05030201u), w2 = __builtin_amdgcn_perm(w3, w0, 0x06050302u);
+            c0[0] = __builtin_amdgcn_udot4(w0, P0, c0[0], false); c1[0] = __builtin_amdgcn_udot4(w0, P1, c1[0], false);
+            c0[1] = __builtin_amdgcn_udot4(w1, P0, c0[1], false); c1[1] = __builtin_amdgcn_udot4(w1, P1, c1[1], false);
+            c0[2] = __builtin_amdgcn_udot4(w2, P0, c0[2], false); c1[2] = __builtin_amdgcn_udot4(w2, P1, c1[2], false);
+            c0[3] = __builtin_amdgcn_udot4(w3, P0, c0[3], false); c1[3] = __builtin_amdgcn_udot4(w3, P1, c1[3], false);
+        };
+        const int tend = has1 ? b : b - 1;                 // (an odd last row: the tile holds no row under its missing partner)
+        for (int t = a; t <= tend; t++) {
+            const lds_u32* p0 = t < b ? pr : zrow;
+            const lds_u32* p1 = (t > a && has1) ? pr - Gp : zrow;
+            int g = 0;
+            for (; g + 4 <= G; g += 4) {                   // the P0 dwords of four groups in one read, for either cell row
+                const v4u32 q0 = *reinterpret_cast<const lds_v4u32*>(p0 + g), q1 = *reinterpret_cast<const lds_v4u32*>(p1 + g);
+                group(q0.x, q1.x, tl + g * 8); group(q0.y, q1.y, tl + g * 8 + 8); group(q0.z, q1.z, tl + g * 8 + 16); group(q0.w, q1.w, tl + g * 8 + 24);
+            }
+            if (G & 2) {
+                const unsigned long long q0 = *reinterpret_cast<const lds_u64*>(p0 + g), q1 = *reinterpret_cast<const lds_u64*>(p1 + g);
+                group((unsigned)q0, (unsigned)q1, tl + g * 8); group((unsigned)(q0 >> 32), (unsigned)(q1 >> 32), tl + g * 8 + 8);
+                g += 2;
+            }
+            if (G & 1) group(p0[g], p1[g], tl + g * 8);
+            tl += (unsigned)tp * 8u;
+            pr += Gp;
+        }
+        if (t0 + lane < ntask) {
+            const int unit = uq * rows + 2 * m;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                __hip_atomic_fetch_add(acc + (k * nunits + unit) * 2, c0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (has1) __hip_atomic_fetch_add(acc + (k * nunits + unit + 1) * 2, c1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
 // What the box sums count too much under a masked template: for every group that drops pixels, the energy of the dropped
 // ones - si -= <window & C, window & C> with C the group's complement mask inside the template - over a list of
 // {C, tile offset} entries padded with null entries to S slices of equal length (tasks as in lean_accumulate).
@@ -529,7 +592,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     const int NGc = R * G;                                 // groups the lists hold at most
     const int cap = lean_cap(NGc);                         // room for the padding entries and for reads a few entries ahead
     // (box: no lists - the P0 dwords of the whole template, or of a chunk and its list of groups that drop pixels, take their place)
-    const int list_bytes = boxm ? (R * lean_pc_pitch(G) * 4 + 15) & ~15 : box ? (L.th * lean_pc_pitch(G) * 4 + 15) & ~15 : cap * 8;
+    const int list_bytes = boxm ? ((R + 1) * lean_pc_pitch(G) * 4 + 15) & ~15 : box ? ((L.th + 1) * lean_pc_pitch(G) * 4 + 15) & ~15 : cap * 8;
     const int marr_bytes = boxm ? lean_ccap(NGc) * 8 : box ? 0 : (lean_mcap(NGc, R, !SEARCH) * 4 + 15) & ~15;
     if (SEARCH && !CHUNKS) {
         // sums fit 32 bits up to 66051 template pixels; a lane's window positions index the tile with 16 bits to spare
@@ -560,6 +623,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
     lds_u32* pc = reinterpret_cast<lds_u32*>(list);        // box: P0 of every group of the template (masked: of the chunk)
     lds_u64* clist = reinterpret_cast<lds_u64*>(marr);     // masked box: {complement mask, tile offset} of the groups that drop pixels
     int ncomp = 0;                                         //   and their number in the current chunk
+    const lds_u32* zrow = pc + (boxm ? R : L.th) * lean_pc_pitch(G);     // box: a row of zero P0 dwords behind the stored rows
 
     STAMP(50);
     // A template of at most 32 groups (the coarse levels of a walk) is not sorted into the two lists: compacting it
@@ -625,6 +689,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             // a mask that drops pixels in more groups than a warped quadrilateral does (the plain build's list has room for those only)
             if (baseC + LEAN_MAX_S + 3 > ccap) { LEAN_REJECT(4); return -1; }
             for (int p2 = baseC + lane; p2 < baseC + LEAN_MAX_S; p2 += SLAM_WG) clist[p2] = 0ull;       // padding: adds nothing
+            for (int p2 = lane; p2 < Gp; p2 += SLAM_WG) pc[R * Gp + p2] = 0u;
             ncomp = baseC;
             if (blk == 0 && ch == nchunk - 1) nm = make_norms(wave_sum_u32(sp_part));       // |P0|^2 of the whole template
             STAMP(52);
@@ -706,6 +771,7 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
             __syncthreads();
             if (i < NG) { const int u = (int)(((float)i + 0.5f) * rG), gq = i - u * G; pc[u * Gp + gq] = P0; }
         }
+        for (int p2 = lane; p2 < Gp; p2 += SLAM_WG) pc[L.th * Gp + p2] = 0u;      // (behind every staged pair that was still to be read)
     } else {
 
     // ---- a handful of lattice cells under a small template (the coarse levels of a walk) --------------------------------
@@ -910,7 +976,11 @@ __device__ __forceinline__ LeanOut lean_level(const LeanLevel& L, lds_u8* lds, i
         __syncthreads();
         STAMP(53);
         if (CHUNKS && box) {
-            lean_accumulate_rows(tile, boxm ? pc : pc + u0 * lean_pc_pitch(G), acc, nunits, lean_pick_row_slices(nunits, Rc, G), Rc, G, rows_b, tp);
+            // two cell rows per unit where a chunk has template rows enough to carry the extra tile row a task then walks
+            // (a 60x40 line area under 20 of a 40x40 template's rows: 0.404 -> 0.365 ms per 3072 lines; chunks of 6 rows of
+            // an 81x81 template: 1.98 -> 2.43 ms per 16384 walks, hence the bound)
+            if (Rc >= 12 && rows_b >= 2) lean_accumulate_rows2(tile, boxm ? pc : pc + u0 * lean_pc_pitch(G), zrow, acc, nunits, Rc, G, rows_b, tp);
+            else lean_accumulate_rows(tile, boxm ? pc : pc + u0 * lean_pc_pitch(G), acc, nunits, lean_pick_row_slices(nunits, Rc, G), Rc, G, rows_b, tp);
             if (boxm) lean_accumulate_dropped(tile, clist, acc, nunits, ncomp, rows_b, tp);
         }
         else if (strips) lean_accumulate<4>(tile, list, marr, acc, nunits, S, na, nb, nA1, rows_b, tp, o, 1);
