@@ -150,6 +150,9 @@ __host__ __device__ __forceinline__ int lean_pc_pitch(int G) { return G >= 3 ? (
 // the same scheme, with the boxes summed out of the LDS tile, measured slower on the templates that build is for: a C2
 // walk 4347 instead of 4104 VALU instructions - 17 cell rows of prefix sums cost more than the 670 dots they replace -
 // and its mere presence in the kernel cost the C2 path 3.6 %; 31x31 templates gained 1 - 2 %.)
+#ifndef LEAN_BOX_MIN_WORK
+#define LEAN_BOX_MIN_WORK 2048
+#endif
 #define LEAN_BOX_NONE 0
 #define LEAN_BOX_UNMASKED 1
 #define LEAN_BOX_MASKED 2
@@ -157,7 +160,7 @@ __host__ __device__ __forceinline__ int lean_box_mode(bool search, bool has_mask
     if (step != 1 || aw + tw - 1 > 2 * SLAM_WG) return LEAN_BOX_NONE;
     if (!has_mask) return search ? LEAN_BOX_UNMASKED : LEAN_BOX_NONE;
     const int G = (tw + 3) >> 2, cols = (aw + 3) >> 2;
-    return !search && !resized && th * G * cols >= 2048 ? LEAN_BOX_MASKED : LEAN_BOX_NONE;
+    return !search && !resized && th * G * cols >= LEAN_BOX_MIN_WORK ? LEAN_BOX_MASKED : LEAN_BOX_NONE;
 }
 
 // Entries of the list of groups that drop pixels inside the template (masked box sums): every group at worst, padding
